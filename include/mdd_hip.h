@@ -1,0 +1,153 @@
+/* mdd_hip.h -- C ABI of libmdd_hip.so: the MI355X (gfx950) engine for the hot path of
+ * kushal-bhargav/multimodal_dataset_distillation: distill.py's inner `syn_steps` unrolled
+ * training + bi-trajectory matching loop.
+ *
+ * Plain pointers and sizes only; all `*_dev` pointers are DEVICE pointers (hipMalloc'ed /
+ * torch.Tensor.data_ptr()), `stream` is a hipStream_t cast to void* (NULL = default stream).
+ * Every function returns 0 on success; on failure it returns non-zero and `mdd_last_error()`
+ * describes it.  HIP out-of-memory is reported with the substring "out of memory" so the
+ * reference's OOM handling (distill.py:525-545, 568-575 matches on that substring) keeps
+ * working when the Python host re-raises it as RuntimeError.
+ *
+ * Reference interface each entry point replaces (file:line in /root/reference):
+ *   mdd_engine_create / _param_*     student construction CLIPModel_full + ReparamModule x2
+ *                                    distill.py:440-442, reparam_module.py:18-75 (flatten order)
+ *   mdd_img_forward                  img_student_net(x, flat_param=theta)   distill.py:524
+ *                                    -> ReparamModule.forward reparam_module.py:148-159
+ *                                    -> ImageEncoder.forward networks.py:678-682 (timm nfnet_l0)
+ *   mdd_txt_forward                  txt_student_net(y, flat_param=theta)   distill.py:537
+ *                                    -> ProjectionHead.forward networks.py:639-646
+ *   mdd_contrastive                  x/||x||, y/||y||, syn_lr_img * x @ y.T, symmetric CE
+ *                                    distill.py:533,546-551
+ *   mdd_img_backward / mdd_txt_backward
+ *                                    torch.autograd.grad(loss, theta, create_graph=True)
+ *                                    distill.py:562-567
+ *   mdd_*_tangent_forward/backward   the double-backward that grand_loss.backward() performs
+ *                                    through those gradients, distill.py:606
+ *   mdd_flat_*                       theta' = theta - lr*g (:582-583), sum-MSE (:588-595),
+ *                                    SGD momentum step (:233-241, :611-613)
+ *   mdd_unrolled_match               the whole iteration distill.py:509-606 in one call
+ */
+#ifndef MDD_HIP_H
+#define MDD_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDD_DTYPE_F32 0  /* fp32 storage + exact-fp32 MFMA (parity mode)                    */
+#define MDD_DTYPE_BF16 1 /* bf16 activations/weights, bf16 MFMA, fp32 accumulate, fp32 theta */
+
+typedef struct mdd_engine mdd_engine;
+
+typedef struct mdd_config {
+  const char* variant; /* "nfnet_l0" | "nfnet_l1" | "nfnet_tiny" */
+  int32_t batch;       /* pairs per inner step (mini_batch_size, distill.py:511)          */
+  int32_t num_queries; /* rows of image_syn / text_syn (distill.py:630)                    */
+  int32_t image_size;  /* square input, multiple of 32                                     */
+  int32_t d_txt;       /* text embedding dim (768 for BERT, networks.py:824)               */
+  int32_t syn_steps;   /* number of activation stashes kept (unroll depth)                 */
+  int32_t dtype;       /* MDD_DTYPE_*                                                      */
+} mdd_config;
+
+const char* mdd_last_error(void);
+int mdd_version(void);
+
+/* ---- engine lifetime and memory (the caller owns device memory: PyTorch caching allocator) */
+int mdd_engine_create(const mdd_config* cfg, mdd_engine** out);
+void mdd_engine_destroy(mdd_engine* e);
+int64_t mdd_engine_workspace_bytes(const mdd_engine* e);
+int mdd_engine_bind_workspace(mdd_engine* e, void* ws_dev, int64_t bytes, void* stream);
+
+/* ---- parameter table in reference flatten order (reparam_module.py:28-39).  which: 0 = image
+ * encoder, 1 = text projection.  shape4 is right-padded with 1s; ndim in *ndim. */
+int64_t mdd_engine_param_numel(const mdd_engine* e, int which);
+int mdd_engine_param_count(const mdd_engine* e, int which);
+int mdd_engine_param_info(const mdd_engine* e, int which, int index, char* name, int name_cap,
+                          int64_t* shape4, int* ndim, int64_t* offset);
+int mdd_engine_feature_dim(const mdd_engine* e);
+/* named stash buffer lookup for tests: byte offset into the bound workspace */
+int mdd_engine_find_buffer(const mdd_engine* e, const char* name, int slot, int64_t* byte_offset,
+                           int64_t* elems, int* is_float32);
+
+/* ---- image encoder passes (slot = inner step index whose activations are kept) */
+int mdd_img_forward(mdd_engine* e, int slot, const float* theta_dev, const float* image_syn_dev,
+                    const int64_t* idx_dev, float* feat_out_dev, void* stream);
+int mdd_img_backward(mdd_engine* e, int slot, const float* theta_dev, const float* feat_bar_dev,
+                     float* gtheta_out_dev, void* stream);
+int mdd_img_tangent_forward(mdd_engine* e, int slot, const float* theta_dev,
+                            const float* theta_dot_dev, float* feat_dot_out_dev, void* stream);
+/* dimage_accum[idx] += coef*mul * d/d(image) ; coef_dev may be NULL (=1) */
+int mdd_img_tangent_backward(mdd_engine* e, int slot, const float* theta_dev,
+                             const float* theta_dot_dev, const float* feat_bar_dot_dev,
+                             float* htheta_out_dev, float* dimage_accum_dev,
+                             const int64_t* idx_dev, const float* coef_dev, float mul,
+                             void* stream);
+
+/* ---- text projection passes; drop_mask_dev: [batch, feat] already scaled by 1/(1-p), or NULL */
+int mdd_txt_forward(mdd_engine* e, int slot, const float* theta_dev, const float* text_syn_dev,
+                    const int64_t* idx_dev, const float* drop_mask_dev, float* feat_out_dev,
+                    void* stream);
+int mdd_txt_backward(mdd_engine* e, int slot, const float* theta_dev, const float* feat_bar_dev,
+                     float* gtheta_out_dev, void* stream);
+int mdd_txt_tangent_forward(mdd_engine* e, int slot, const float* theta_dev,
+                            const float* theta_dot_dev, float* feat_dot_out_dev, void* stream);
+int mdd_txt_tangent_backward(mdd_engine* e, int slot, const float* theta_dev,
+                             const float* theta_dot_dev, const float* feat_bar_dot_dev,
+                             float* htheta_out_dev, float* dtext_accum_dev, const int64_t* idx_dev,
+                             const float* coef_dev, float mul, void* stream);
+
+/* ---- contrastive head: loss + d/dx, d/dy, d/dscale; tangent variant when x_dot/y_dot given.
+ * scale_dev NULL => scale_const is used (upstream distill_original.py:430 behaviour). */
+int mdd_contrastive(mdd_engine* e, const float* x_dev, const float* y_dev, const float* scale_dev,
+                    float scale_const, float* loss_dev, float* xbar_dev, float* ybar_dev,
+                    float* sbar_dev, void* stream);
+int mdd_contrastive_tangent(mdd_engine* e, const float* x_dev, const float* y_dev,
+                            const float* x_dot_dev, const float* y_dot_dev, const float* scale_dev,
+                            float scale_const, float* xbar_dot_dev, float* ybar_dot_dev,
+                            float* sbar_dot_dev, void* stream);
+
+/* ---- flat fp32 parameter streams */
+int mdd_flat_axpy(float* out_dev, const float* x_dev, const float* g_dev, const float* lr_dev,
+                  float sign, int64_t n, void* stream);       /* out = x + sign*lr*g */
+int mdd_flat_sqdist(const float* a_dev, const float* b_dev, double* out_dev, int64_t n,
+                    void* stream);                             /* out[0] += sum (a-b)^2 */
+int mdd_flat_sgd_momentum(float* p_dev, const float* g_dev, float* buf_dev, float lr, float mom,
+                          int first, int64_t n, void* stream);
+
+/* ---- one whole outer iteration (reference distill.py:509-606) */
+typedef struct mdd_iter_args {
+  const float* image_syn;    /* [num_queries,3,S,S] fp32 NCHW                                  */
+  const float* text_syn;     /* [num_queries,d_txt]                                            */
+  const float* lr_img;       /* device scalar syn_lr_img (also the logit scale, distill.py:548) */
+  const float* lr_txt;       /* device scalar syn_lr_txt                                       */
+  const float* theta0_img;   /* expert start  (distill.py:473-476)                             */
+  const float* theta0_txt;
+  const float* target_img;   /* expert target (distill.py:469-472)                             */
+  const float* target_txt;
+  const int64_t* perms;      /* [syn_steps, batch] minibatch indices (distill.py:510-511)      */
+  const float* drop_masks;   /* [syn_steps, batch, feat] or NULL                               */
+  int32_t syn_steps;
+  int32_t use_lr_as_scale;   /* 1: fork behaviour (:548); 0: use logit_scale_const             */
+  float logit_scale_const;
+  float* grad_image_syn;     /* out, same shape as image_syn (overwritten)                     */
+  float* grad_text_syn;      /* out                                                            */
+  float* grad_lr;            /* out [2]: d/d lr_img, d/d lr_txt                                */
+  float* losses;             /* out [3 + syn_steps]: grand, img, txt, contrastive per step     */
+} mdd_iter_args;
+int mdd_unrolled_match(mdd_engine* e, const mdd_iter_args* a, void* stream);
+
+/* ---- single-op entry points (parity tests; NHWC activations, dtype = MDD_DTYPE_*) */
+int mdd_op_conv2d(int dtype, int transposed, int nimg, int hin, int win, int cin, int cout, int k,
+                  int stride, int pad, int groups, const void* a_dev, const void* w_packed_dev,
+                  const float* bias_dev, void* out_dev, void* stream);
+int mdd_op_conv2d_wgrad(int dtype, int nimg, int hin, int win, int cin, int cout, int k, int stride,
+                        int pad, int groups, const void* dy_dev, const void* x_dev,
+                        float* dw_packed_dev, float* dbias_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDD_HIP_H */

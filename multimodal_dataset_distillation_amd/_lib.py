@@ -1,0 +1,89 @@
+"""ctypes binding of the C-ABI library libmdd_hip.so (include/mdd_hip.h).
+
+There is NO fallback: if the HIP library is missing or fails to load, importing the product
+path raises.  PyTorch only supplies device memory (`tensor.data_ptr()`) and the HIP stream.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmdd_hip.so")
+
+DTYPE_F32, DTYPE_BF16 = 0, 1
+
+
+class MddConfig(C.Structure):
+    _fields_ = [("variant", C.c_char_p), ("batch", C.c_int32), ("num_queries", C.c_int32),
+                ("image_size", C.c_int32), ("d_txt", C.c_int32), ("syn_steps", C.c_int32),
+                ("dtype", C.c_int32)]
+
+
+class MddIterArgs(C.Structure):
+    _fields_ = [("image_syn", C.c_void_p), ("text_syn", C.c_void_p), ("lr_img", C.c_void_p),
+                ("lr_txt", C.c_void_p), ("theta0_img", C.c_void_p), ("theta0_txt", C.c_void_p),
+                ("target_img", C.c_void_p), ("target_txt", C.c_void_p), ("perms", C.c_void_p),
+                ("drop_masks", C.c_void_p), ("syn_steps", C.c_int32),
+                ("use_lr_as_scale", C.c_int32), ("logit_scale_const", C.c_float),
+                ("grad_image_syn", C.c_void_p), ("grad_text_syn", C.c_void_p),
+                ("grad_lr", C.c_void_p), ("losses", C.c_void_p)]
+
+
+# every symbol include/mdd_hip.h declares: name -> (restype, argtypes)
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+SIGNATURES = {
+    "mdd_last_error": (C.c_char_p, []),
+    "mdd_version": (_I, []),
+    "mdd_engine_create": (_I, [C.POINTER(MddConfig), C.POINTER(_P)]),
+    "mdd_engine_destroy": (None, [_P]),
+    "mdd_engine_workspace_bytes": (_L, [_P]),
+    "mdd_engine_bind_workspace": (_I, [_P, _P, _L, _P]),
+    "mdd_engine_param_numel": (_L, [_P, _I]),
+    "mdd_engine_param_count": (_I, [_P, _I]),
+    "mdd_engine_param_info": (_I, [_P, _I, _I, C.c_char_p, _I, C.POINTER(_L), C.POINTER(_I),
+                                   C.POINTER(_L)]),
+    "mdd_engine_feature_dim": (_I, [_P]),
+    "mdd_engine_find_buffer": (_I, [_P, C.c_char_p, _I, C.POINTER(_L), C.POINTER(_L),
+                                    C.POINTER(_I)]),
+    "mdd_img_forward": (_I, [_P, _I, _P, _P, _P, _P, _P]),
+    "mdd_img_backward": (_I, [_P, _I, _P, _P, _P, _P]),
+    "mdd_img_tangent_forward": (_I, [_P, _I, _P, _P, _P, _P]),
+    "mdd_img_tangent_backward": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P]),
+    "mdd_txt_forward": (_I, [_P, _I, _P, _P, _P, _P, _P, _P]),
+    "mdd_txt_backward": (_I, [_P, _I, _P, _P, _P, _P]),
+    "mdd_txt_tangent_forward": (_I, [_P, _I, _P, _P, _P, _P]),
+    "mdd_txt_tangent_backward": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P]),
+    "mdd_contrastive": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P]),
+    "mdd_contrastive_tangent": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P]),
+    "mdd_flat_axpy": (_I, [_P, _P, _P, _P, _F, _L, _P]),
+    "mdd_flat_sqdist": (_I, [_P, _P, _P, _L, _P]),
+    "mdd_flat_sgd_momentum": (_I, [_P, _P, _P, _F, _F, _I, _L, _P]),
+    "mdd_unrolled_match": (_I, [_P, C.POINTER(MddIterArgs), _P]),
+    "mdd_op_conv2d": (_I, [_I] * 11 + [_P, _P, _P, _P, _P]),
+    "mdd_op_conv2d_wgrad": (_I, [_I] * 10 + [_P, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmdd_hip.so and bind every declared symbol.  Raises (never falls back)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libmdd_hip.so is not built (%s). Run `python -m multimodal_dataset_distillation_amd."
+            "build_ext` (needs hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().mdd_last_error().decode("utf-8", "replace")
+        raise RuntimeError("mdd_hip error %d: %s" % (rc, msg))

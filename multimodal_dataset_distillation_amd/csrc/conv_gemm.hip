@@ -1,0 +1,278 @@
+// Implicit-GEMM convolution for gfx950 (CDNA4) MFMA -- forward and data-gradient in ONE kernel.
+//
+//   out[m, g*nc + n] = sum_{tap, kc}  A[src(m, tap), g*kc_ + kc] * B[g][n][tap][kc]
+//
+//   m   = output pixel (image, oy, ox) on NHWC activations (channels contiguous)
+//   src = forward gather (oy*s - p + ty, ...) or transposed/dgrad gather ((oy + p - ty)/s, ...)
+//   B   = packed standardised weights from ws.hip: wf [cout][k*k][cin_g] for forward,
+//         wt [g][cin_g][k*k][cout_g] for dgrad -- K contiguous per output channel in both.
+//   optional second source pair (A2,B2) accumulates into the same MFMA accumulators: that is how
+//   the tangent pass computes  conv(a_dot, w_hat) + conv(a, w_hat_dot)  in one launch.
+//
+// Tiling: 256 threads = 4 waves (64 lanes).  Block tile BM x BN, K-step = one 128-byte row of K
+// (64 bf16 / 32 f32), LDS double-buffered, next tile's global loads issued before the MFMA
+// phase (register staging: the gather needs zero-fill at image borders).  LDS rows are 128 B =
+// 8 chunks of 16 B; chunk position is XOR-swizzled with (row>>1)&7 so that every 16-lane group
+// of a ds_read_b128 hits 16 distinct 16-byte slots of the 256-byte bank row (conflict-free).
+// bf16: v_mfma_f32_32x32x16_bf16 ; f32 (parity mode): v_mfma_f32_32x32x2_f32 (exact fp32 FMA).
+// Fused epilogues (ConvEpi): bias, SiLU*beta, SiLU' / SiLU'' chain rule, residual adds.
+#include "kernels.h"
+
+namespace {
+
+template <class AT> struct Mma;
+template <> struct Mma<bf16> {
+  static constexpr int KE = 64;  // K elements per 128-byte row
+  static constexpr int CE = 8;   // elements per 16-byte chunk
+  static DEVI void step(const uint4& a, const uint4& b, f32x16& acc) {
+    bf16x8 av = __builtin_bit_cast(bf16x8, a), bv = __builtin_bit_cast(bf16x8, b);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static constexpr int KE = 32;
+  static constexpr int CE = 4;
+  static DEVI void step(const uint4& a, const uint4& b, f32x16& acc) {
+    // lane-half h holds k = 4*(2q+h)+j, j=0..3 for BOTH operands: any k-permutation that is the
+    // same for A and B leaves the sum unchanged.
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  }
+};
+
+DEVI int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+struct KArgs {
+  const void* A1; const void* B1; const void* A2; const void* B2;
+  ConvGeom g;
+  ConvEpi ep;
+  int M, mtiles, ntiles;
+};
+
+template <class AT, int WGM, int WGN, int TM, int TN>
+__global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
+  constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+  constexpr int RA = BM / 32, RB = BN / 32;
+  constexpr int KE = Mma<AT>::KE, CE = Mma<AT>::CE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* As = smem;                 // 2 * BM * 128
+  char* Bs = smem + 2 * BM * 128;  // 2 * BN * 128
+
+  const ConvGeom& G = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave - wm * WGN;
+
+  // block -> (m tile, group, n tile); n tile fastest so neighbours share the A panel in L2
+  int bid = blockIdx.x;
+  const int nt = bid % p.ntiles; bid /= p.ntiles;
+  const int grp = bid % G.groups;
+  const int mt = bid / G.groups;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int ktot = G.k * G.k * G.kc;
+  const int nk1 = (ktot + KE - 1) / KE;
+  const int nk = p.A2 ? 2 * nk1 : nk1;
+
+  // ---- per-thread staging geometry (fixed across the K loop)
+  const int cj = tid & 7, r0 = tid >> 3;
+  int pbase[RA], pby[RA], pbx[RA];
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    int m = m0 + r0 + 32 * i;
+    if (m < p.M) {
+      int ox = m % G.wo;
+      int t = m / G.wo;
+      int oy = t % G.ho;
+      int ni = t / G.ho;
+      pbase[i] = ni * G.ha * G.wa;
+      if (G.transposed) { pby[i] = oy + G.pad; pbx[i] = ox + G.pad; }
+      else { pby[i] = oy * G.stride - G.pad; pbx[i] = ox * G.stride - G.pad; }
+    } else {
+      pbase[i] = 0; pby[i] = -(1 << 20); pbx[i] = -(1 << 20);
+    }
+  }
+  const int sh = G.stride >> 1;  // stride in {1,2}
+
+  uint4 ra[RA], rb[RB];
+  auto load_tile = [&](int kt) {
+    const AT* A = (const AT*)(kt < nk1 ? p.A1 : p.A2);
+    const AT* B = (const AT*)(kt < nk1 ? p.B1 : p.B2);
+    int kidx = (kt < nk1 ? kt : kt - nk1) * KE + cj * CE;
+    bool kok = kidx < ktot;
+    int tap = kidx / G.kc;
+    int kcq = kidx - tap * G.kc;
+    int ty = tap / G.k, tx = tap - ty * G.k;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      int iy, ix;
+      bool ok = kok;
+      if (G.transposed) {
+        int ny = pby[i] - ty, nx = pbx[i] - tx;
+        ok = ok && ny >= 0 && nx >= 0 && ((ny | nx) & (G.stride - 1)) == 0;
+        iy = ny >> sh; ix = nx >> sh;
+        ok = ok && iy < G.ha && ix < G.wa;
+      } else {
+        iy = pby[i] + ty; ix = pbx[i] + tx;
+        ok = ok && (unsigned)iy < (unsigned)G.ha && (unsigned)ix < (unsigned)G.wa;
+      }
+      if (ok) {
+        size_t off = ((size_t)(pbase[i] + iy * G.wa + ix)) * G.ca_tot + grp * G.kc + kcq;
+        ra[i] = *(const uint4*)(A + off);
+      } else {
+        ra[i] = make_uint4(0, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      int n = n0 + r0 + 32 * i;
+      if (kok && n < G.nc) {
+        size_t off = ((size_t)(grp * G.nc + n)) * ktot + kidx;
+        rb[i] = *(const uint4*)(B + off);
+      } else {
+        rb[i] = make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* a = As + buf * BM * 128;
+    char* b = Bs + buf * BN * 128;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) *(uint4*)(a + lds_off(r0 + 32 * i, cj)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) *(uint4*)(b + lds_off(r0 + 32 * i, cj)) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const char* a = As + buf * BM * 128;
+    const char* b = Bs + buf * BN * 128;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[i] = *(const uint4*)(a + lds_off((wm * TM + i) * 32 + l31, 2 * q + lh));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bf[j] = *(const uint4*)(b + lds_off((wn * TN + j) * 32 + l31, 2 * q + lh));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mma<AT>::step(af[i], bf[j], acc[i][j]);
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const ConvEpi& E = p.ep;
+  AT* out_raw = (AT*)E.out_raw;
+  AT* out_act = (AT*)E.out_act;
+  const AT* Cst = (const AT*)E.c;
+  const AT* Ct = (const AT*)E.c_t;
+  const AT* Ab = (const AT*)E.abar;
+  const AT* add1 = (const AT*)E.add1;
+  const AT* add2 = (const AT*)E.add2;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    int n = n0 + (wn * TN + j) * 32 + l31;
+    if (n >= G.nc) continue;
+    int ch = grp * G.nc + n;
+    float bias = 0.f;
+    if (E.mode == EPI_FWD && E.bias) bias = E.bias[ch];
+    if (E.mode == EPI_FWD_T && E.bias_t) bias = E.bias_t[ch];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= p.M) continue;
+        size_t idx = (size_t)m * G.co_tot + ch;
+        float v = acc[i][j][r] + bias;
+        if (add1) v += to_f(add1[idx]);
+        switch (E.mode) {
+          case EPI_FWD:
+            if (out_raw) out_raw[idx] = from_f<AT>(v);
+            if (out_act) out_act[idx] = from_f<AT>(E.beta * silu_(v));
+            break;
+          case EPI_FWD_T:
+            if (out_raw) out_raw[idx] = from_f<AT>(v);
+            if (out_act) out_act[idx] = from_f<AT>(E.beta * dsilu_(to_f(Cst[idx])) * v);
+            break;
+          case EPI_BWD: {
+            if (out_raw) out_raw[idx] = from_f<AT>(v);
+            if (out_act) {
+              float o = E.beta * dsilu_(to_f(Cst[idx])) * v;
+              if (add2) o += to_f(add2[idx]);
+              out_act[idx] = from_f<AT>(o);
+            }
+          } break;
+          case EPI_BWD_T: {
+            if (out_raw) out_raw[idx] = from_f<AT>(v);
+            Dual cd(to_f(Cst[idx]), to_f(Ct[idx]));
+            Dual ad(to_f(Ab[idx]), v);
+            float o = E.beta * (dsilu_(cd) * ad).t;
+            if (add2) o += to_f(add2[idx]);
+            out_act[idx] = from_f<AT>(o);
+          } break;
+          default:  // EPI_BWD_LIN
+            out_raw[idx] = from_f<AT>(v);
+            break;
+        }
+      }
+    }
+  }
+}
+
+template <class AT, int WGM, int WGN, int TM, int TN>
+void launch_cfg(const KArgs& a, hipStream_t st) {
+  constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+  KArgs k = a;
+  k.mtiles = (a.M + BM - 1) / BM;
+  k.ntiles = (a.g.nc + BN - 1) / BN;
+  size_t shm = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_conv_gemm<AT, WGM, WGN, TM, TN>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    attr_set = true;
+  }
+  int64_t blocks = (int64_t)k.mtiles * k.ntiles * a.g.groups;
+  k_conv_gemm<AT, WGM, WGN, TM, TN><<<(unsigned)blocks, 256, shm, st>>>(k);
+}
+
+}  // namespace
+
+template <class AT>
+void launch_conv_gemm(const ConvGeom& g, const AT* A1, const AT* B1, const AT* A2, const AT* B2,
+                      const ConvEpi& ep, hipStream_t st) {
+  KArgs a;
+  a.A1 = A1; a.B1 = B1; a.A2 = A2; a.B2 = B2;
+  a.g = g; a.ep = ep;
+  a.M = g.nimg * g.ho * g.wo;
+  a.mtiles = a.ntiles = 0;
+  // tile selection by output-channel width per group
+  if (g.nc <= 32) launch_cfg<AT, 4, 1, 1, 1>(a, st);        // 128 x 32  (stem)
+  else if (g.nc <= 64) launch_cfg<AT, 4, 1, 2, 2>(a, st);   // 256 x 64  (group width 64)
+  else launch_cfg<AT, 2, 2, 2, 2>(a, st);                   // 128 x 128
+}
+template void launch_conv_gemm<float>(const ConvGeom&, const float*, const float*, const float*,
+                                      const float*, const ConvEpi&, hipStream_t);
+template void launch_conv_gemm<bf16>(const ConvGeom&, const bf16*, const bf16*, const bf16*,
+                                     const bf16*, const ConvEpi&, hipStream_t);

@@ -1,0 +1,287 @@
+// Weight-gradient contraction of a convolution on NHWC activations, gfx950 MFMA.
+//
+//   dW[g][co][tap][kc] += sum_m dy[m, g*nc+co] * x[src(m,tap), g*kc_+kc]      (m = output pixel)
+//
+// Both operands have the REDUCTION index m as their slow (strided) dimension, so MFMA fragments
+// need "k along rows" data:
+//   f32 : v_mfma_f32_32x32x2_f32 takes one f32 per lane -- lane (i, k) reads LDS[row 2t+k][col i],
+//         consecutive lanes hit consecutive dwords (conflict-free, no transpose needed).
+//   bf16: v_mfma_f32_16x16x32_bf16 fragments are fetched with ds_read_b64_tr_b16 (the CDNA4
+//         LDS transpose read): a 16-lane group reads a 4-row x 16-col block and each lane gets one
+//         column.  Which 4-row block of the 32-row K-tile a group reads per instruction is a free
+//         k-permutation (same for A and B); it is chosen so the two groups of a half-wave read
+//         rows 8x..8x+3 and 8x+4..8x+7, which with the XOR swizzle below is bank-conflict-free.
+// The M range is split across blockIdx.y and combined with fp32 atomics (dW is zeroed by the
+// caller): per block at most 64x128 atomics per M-chunk of >= 256 pixels.
+// An optional second pair (dy2, x2) is accumulated too (tangent pass), and the bias gradient
+// (column sums of dy1) is taken from the staging registers of the k'-tile-0 blocks.
+#include "kernels.h"
+
+namespace {
+
+constexpr int BCO = 64;    // output-channel tile
+constexpr int BKP = 128;   // k' = (tap, kc) tile
+constexpr int BKM = 32;    // pixels per K-step
+
+struct WArgs {
+  const void* dy1; const void* x1; const void* dy2; const void* x2;
+  float* dW; float* dbias;
+  ConvGeom g;
+  int M, cotiles, kptiles, mchunk;
+};
+
+template <class AT> struct WT;
+template <> struct WT<bf16> { static constexpr int CE = 8; };
+template <> struct WT<float> { static constexpr int CE = 4; };
+
+// LDS chunk swizzle (bf16 path only): rows of ROWB bytes
+template <int ROWB> DEVI int wswz(int row) { return ROWB == 128 ? ((row >> 1) & 3) : (row & 7); }
+
+template <class AT>
+__global__ __launch_bounds__(256) void k_conv_wgrad(const WArgs p) {
+  constexpr int CE = WT<AT>::CE;
+  constexpr bool BF = sizeof(AT) == 2;
+  constexpr int DCH = BCO / CE, XCH = BKP / CE;          // chunks per row
+  constexpr int DROWB = BCO * sizeof(AT), XROWB = BKP * sizeof(AT);
+  constexpr int DSL = (BKM * DCH) / 256 > 0 ? (BKM * DCH) / 256 : 1;  // dy chunks per thread
+  constexpr int XSL = (BKM * XCH) / 256;                              // x chunks per thread
+  constexpr int DTILE = BKM * DROWB, XTILE = BKM * XROWB;
+  __shared__ __attribute__((aligned(16))) char smem[2 * (DTILE + XTILE)];
+  char* Ds = smem;
+  char* Xs = smem + 2 * DTILE;
+
+  const ConvGeom& G = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  const int kpt = bid % p.kptiles; bid /= p.kptiles;
+  const int cot = bid % p.cotiles;
+  const int grp = bid / p.cotiles;
+  const int co0 = cot * BCO, kp0 = kpt * BKP;
+  const int ktot = G.k * G.k * G.kc;
+  const int mbeg = blockIdx.y * p.mchunk;
+  const int mend = min(p.M, mbeg + p.mchunk);
+  const int niter1 = (mend - mbeg + BKM - 1) / BKM;
+  const int niter = p.dy2 ? 2 * niter1 : niter1;
+
+  // ---- staging geometry.  dy: chunk col dcol, rows drow + (256/DCH)*i ; x: xcol, xrow + (256/XCH)*i
+  const int dcol = tid % DCH, drow = tid / DCH;
+  const int xcol = tid % XCH, xrow = tid / XCH;
+  constexpr int DSTEP = 256 / DCH, XSTEP = 256 / XCH;
+  // x chunk -> (tap, kc) is iteration-invariant
+  const int kp = kp0 + xcol * CE;
+  const bool kp_ok = kp < ktot;
+  const int tap = kp / G.kc, kcq = kp - tap * G.kc;
+  const int ty = tap / G.k, tx = tap - ty * G.k;
+  const bool dco_ok = (co0 + dcol * CE) < G.nc;
+
+  uint4 rd[DSL], rx[XSL];
+  float bsum[CE];
+#pragma unroll
+  for (int e = 0; e < CE; ++e) bsum[e] = 0.f;
+  const bool do_bias = p.dbias != nullptr && kpt == 0;
+
+  auto load_tile = [&](int it) {
+    const bool second = it >= niter1;
+    const AT* DY = (const AT*)(second ? p.dy2 : p.dy1);
+    const AT* X = (const AT*)(second ? p.x2 : p.x1);
+    const int mb = mbeg + (second ? it - niter1 : it) * BKM;
+#pragma unroll
+    for (int i = 0; i < DSL; ++i) {
+      int m = mb + drow + DSTEP * i;
+      if (m < mend && dco_ok && (drow + DSTEP * i) < BKM) {
+        rd[i] = *(const uint4*)(DY + (size_t)m * G.co_tot + grp * G.nc + co0 + dcol * CE);
+        if (do_bias && !second) {
+          float f[CE];
+          Chunk<AT>::unpack(rd[i], f);
+#pragma unroll
+          for (int e = 0; e < CE; ++e) bsum[e] += f[e];
+        }
+      } else {
+        rd[i] = make_uint4(0, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < XSL; ++i) {
+      int m = mb + xrow + XSTEP * i;
+      bool ok = kp_ok && m < mend;
+      if (ok) {
+        int ox = m % G.wo;
+        int t = m / G.wo;
+        int oy = t % G.ho;
+        int ni = t / G.ho;
+        int iy = oy * G.stride - G.pad + ty, ix = ox * G.stride - G.pad + tx;
+        ok = (unsigned)iy < (unsigned)G.ha && (unsigned)ix < (unsigned)G.wa;
+        if (ok)
+          rx[i] = *(const uint4*)(X + ((size_t)(ni * G.ha + iy) * G.wa + ix) * G.ca_tot +
+                                  grp * G.kc + kcq);
+      }
+      if (!ok) rx[i] = make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* d = Ds + buf * DTILE;
+    char* x = Xs + buf * XTILE;
+#pragma unroll
+    for (int i = 0; i < DSL; ++i) {
+      int r = drow + DSTEP * i;
+      if (r < BKM) {
+        int c = BF ? (dcol ^ (wswz<DROWB>(r) << 1)) : dcol;
+        *(uint4*)(d + r * DROWB + c * 16) = rd[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < XSL; ++i) {
+      int r = xrow + XSTEP * i;
+      int c = BF ? (xcol ^ (wswz<XROWB>(r) << 1)) : xcol;
+      *(uint4*)(x + r * XROWB + c * 16) = rx[i];
+    }
+  };
+
+  // accumulators: f32 -> 2 blocks of 32x32 (co 0..31, 32..63) x (32 k' of this wave)
+  //               bf16 -> 4x2 blocks of 16x16
+  f32x16 accf[2];
+  f32x4 accb[4][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accf[i][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) accb[i][j][r] = 0.f;
+
+  if (niter > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  for (int it = 0; it < niter; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < niter) load_tile(it + 1);
+    const char* d = Ds + buf * DTILE;
+    const char* x = Xs + buf * XTILE;
+    if constexpr (!BF) {
+      const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+      for (int t = 0; t < BKM / 2; ++t) {
+        int r = 2 * t + lh;
+        float a0 = *(const float*)(d + r * DROWB + l31 * 4);
+        float a1 = *(const float*)(d + r * DROWB + (32 + l31) * 4);
+        float b = *(const float*)(x + r * XROWB + (wave * 32 + l31) * 4);
+        accf[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, accf[0], 0, 0, 0);
+        accf[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, accf[1], 0, 0, 0);
+      }
+    } else {
+      const int gq = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+      // 4-row block read by this lane group in instruction e: rho(g,e) = 2*(2e + (g>>1)) + (g&1)
+      s16x4 af[4][2], bfr[2][2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        int row = 4 * (2 * (2 * e + (gq >> 1)) + (gq & 1)) + q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int unit = (16 * i + 4 * pp) >> 2;  // 8-byte unit index within the row
+          int u = unit ^ (wswz<DROWB>(row) << 2);
+          af[i][e] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(d + row * DROWB + u * 8));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          int unit = (wave * 32 + 16 * j + 4 * pp) >> 2;
+          int u = unit ^ (wswz<XROWB>(row) << 2);
+          bfr[j][e] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(x + row * XROWB + u * 8));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          s16x8 a8 = __builtin_shufflevector(af[i][0], af[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
+          s16x8 b8 = __builtin_shufflevector(bfr[j][0], bfr[j][1], 0, 1, 2, 3, 4, 5, 6, 7);
+          accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(bf16x8, a8), __builtin_bit_cast(bf16x8, b8), accb[i][j], 0, 0, 0);
+        }
+    }
+    if (it + 1 < niter) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- write-out: fp32 atomics into dW[g][co][k']
+  float* dWg = p.dW + (size_t)grp * G.nc * ktot;
+  if constexpr (!BF) {
+    const int l31 = lane & 31, lh = lane >> 5;
+    int kcol = kp0 + wave * 32 + l31;
+    if (kcol < ktot) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int co = co0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (co < G.nc) atomicAdd(dWg + (size_t)co * ktot + kcol, accf[i][r]);
+        }
+    }
+  } else {
+    const int gq = lane >> 4, li = lane & 15;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int kcol = kp0 + wave * 32 + 16 * j + li;
+      if (kcol >= ktot) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int co = co0 + 16 * i + 4 * gq + r;
+          if (co < G.nc) atomicAdd(dWg + (size_t)co * ktot + kcol, accb[i][j][r]);
+        }
+    }
+  }
+
+  // ---- bias gradient: reduce the per-thread column sums over the rows that share a column
+  if (do_bias) {
+    __syncthreads();
+    float* sh = (float*)smem;  // [DSTEP rows][DCH cols][CE]
+#pragma unroll
+    for (int e = 0; e < CE; ++e) sh[(drow * DCH + dcol) * CE + e] = bsum[e];
+    __syncthreads();
+    if (tid < BCO) {
+      int c = tid / CE, e = tid - c * CE;
+      float s = 0.f;
+      for (int r = 0; r < DSTEP; ++r) s += sh[(r * DCH + c) * CE + e];
+      if (co0 + tid < G.nc) atomicAdd(p.dbias + grp * G.nc + co0 + tid, s);
+    }
+  }
+}
+
+}  // namespace
+
+template <class AT>
+void launch_conv_wgrad(const ConvGeom& g, const AT* dy1, const AT* x1, const AT* dy2, const AT* x2,
+                       float* dW, float* dbias, hipStream_t st) {
+  WArgs a;
+  a.dy1 = dy1; a.x1 = x1; a.dy2 = dy2; a.x2 = x2; a.dW = dW; a.dbias = dbias;
+  a.g = g;
+  a.M = g.nimg * g.ho * g.wo;
+  int ktot = g.k * g.k * g.kc;
+  a.cotiles = (g.nc + BCO - 1) / BCO;
+  a.kptiles = (ktot + BKP - 1) / BKP;
+  int tiles = a.cotiles * a.kptiles * g.groups;
+  int splits = (1536 + tiles - 1) / tiles;
+  int maxsplits = (a.M + 255) / 256;
+  if (splits > maxsplits) splits = maxsplits;
+  if (splits < 1) splits = 1;
+  int mchunk = (a.M + splits - 1) / splits;
+  mchunk = ((mchunk + BKM - 1) / BKM) * BKM;
+  splits = (a.M + mchunk - 1) / mchunk;
+  a.mchunk = mchunk;
+  dim3 grid(tiles, splits);
+  k_conv_wgrad<AT><<<grid, 256, 0, st>>>(a);
+}
+template void launch_conv_wgrad<float>(const ConvGeom&, const float*, const float*, const float*,
+                                       const float*, float*, float*, hipStream_t);
+template void launch_conv_wgrad<bf16>(const ConvGeom&, const bf16*, const bf16*, const bf16*,
+                                      const bf16*, float*, float*, hipStream_t);

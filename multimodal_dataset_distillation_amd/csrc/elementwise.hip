@@ -1,0 +1,425 @@
+// HBM-bound NHWC elementwise / reduction kernels of the NFNet image path (everything that is not a
+// conv contraction): input gather, shortcut average pool, squeeze-excite pooling / gating /
+// residual, final global pool -- each with its backward, and (S = Dual) its tangent.
+// All tensors are [n, h*w, c] with c contiguous; every access is a 16-byte chunk per lane.
+#include "kernels.h"
+
+namespace {
+
+template <class AT> DEVI void ld_chunk(const AT* p, int64_t chunk_idx, float* f) {
+  uint4 v = ((const uint4*)p)[chunk_idx];
+  Chunk<AT>::unpack(v, f);
+}
+template <class AT> DEVI void st_chunk(AT* p, int64_t chunk_idx, const float* f) {
+  ((uint4*)p)[chunk_idx] = Chunk<AT>::pack(f);
+}
+template <class S, class AT>
+DEVI void ld_chunkS(const AT* pv, const AT* pt, int64_t ci, S* out) {
+  constexpr int CE = Chunk<AT>::N;
+  float a[CE], b[CE];
+  ld_chunk<AT>(pv, ci, a);
+  if constexpr (IsDual<S>::v) {
+    ld_chunk<AT>(pt, ci, b);
+#pragma unroll
+    for (int i = 0; i < CE; ++i) out[i] = Dual(a[i], b[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < CE; ++i) out[i] = a[i];
+  }
+}
+// Dual: store tangent to pt ; float: store to pv
+template <class S, class AT> DEVI void st_chunkS(AT* pv, AT* pt, int64_t ci, const S* x) {
+  constexpr int CE = Chunk<AT>::N;
+  float a[CE];
+  if constexpr (IsDual<S>::v) {
+#pragma unroll
+    for (int i = 0; i < CE; ++i) a[i] = x[i].t;
+    st_chunk<AT>(pt, ci, a);
+  } else {
+#pragma unroll
+    for (int i = 0; i < CE; ++i) a[i] = x[i];
+    st_chunk<AT>(pv, ci, a);
+  }
+}
+
+inline int egrid(int64_t items, int block = 256) {
+  int64_t g = (items + block - 1) / block;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ------------------------------------------------------------------ image gather / scatter
+// reference distill.py:510-513 (x = syn_images[these_indices]) fused with NCHW fp32 -> NHWC AT.
+template <class AT>
+__global__ void k_img_gather(AT* __restrict__ x0, const float* __restrict__ image,
+                             const int64_t* __restrict__ idx, int n, int c, int h, int w, int cpad) {
+  int64_t total = (int64_t)n * h * w;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t hw = i % ((int64_t)h * w);
+    int ni = (int)(i / ((int64_t)h * w));
+    int64_t src_n = idx ? idx[ni] : ni;
+    const float* src = image + (src_n * c) * (int64_t)h * w + hw;
+    for (int cc = 0; cc < cpad; ++cc)
+      x0[i * cpad + cc] = from_f<AT>(cc < c ? src[(int64_t)cc * h * w] : 0.f);
+  }
+}
+// dimage[idx[n], c, h, w] += coef*mul * x0bar[n, h, w, c]   (idx rows are distinct within a step)
+template <class AT>
+__global__ void k_img_scatter(float* __restrict__ dimage, const AT* __restrict__ x0bar,
+                              const int64_t* __restrict__ idx, const float* __restrict__ coef,
+                              float mul, int n, int c, int h, int w, int cpad) {
+  const float a = mul * (coef ? coef[0] : 1.f);
+  int64_t total = (int64_t)n * h * w;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t hw = i % ((int64_t)h * w);
+    int ni = (int)(i / ((int64_t)h * w));
+    int64_t dst_n = idx ? idx[ni] : ni;
+    float* dst = dimage + (dst_n * c) * (int64_t)h * w + hw;
+    for (int cc = 0; cc < c; ++cc) dst[(int64_t)cc * h * w] += a * to_f(x0bar[i * cpad + cc]);
+  }
+}
+
+// ------------------------------------------------------------------ AvgPool2d(2, stride, ceil_mode, count_include_pad=False)
+template <class AT>
+__global__ void k_avgpool2(AT* __restrict__ out, const AT* __restrict__ in, int n, int h, int w,
+                           int c, int stride, int ho, int wo) {
+  constexpr int CE = Chunk<AT>::N;
+  int cch = c / CE;
+  int64_t total = (int64_t)n * ho * wo * cch;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int cc = (int)(i % cch);
+    int64_t p = i / cch;
+    int ox = (int)(p % wo);
+    int oy = (int)((p / wo) % ho);
+    int ni = (int)(p / ((int64_t)wo * ho));
+    float acc[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) acc[e] = 0.f;
+    int cnt = 0;
+    for (int dy = 0; dy < 2; ++dy)
+      for (int dx = 0; dx < 2; ++dx) {
+        int iy = oy * stride + dy, ix = ox * stride + dx;
+        if (iy < h && ix < w) {
+          float f[CE];
+          ld_chunk<AT>(in, (((int64_t)ni * h + iy) * w + ix) * cch + cc, f);
+#pragma unroll
+          for (int e = 0; e < CE; ++e) acc[e] += f[e];
+          ++cnt;
+        }
+      }
+    float r = 1.f / cnt;
+#pragma unroll
+    for (int e = 0; e < CE; ++e) acc[e] *= r;
+    st_chunk<AT>(out, i, acc);
+  }
+}
+// stride == 2 only (non-overlapping windows): din[iy,ix] = dout[iy/2, ix/2] / count
+template <class AT>
+__global__ void k_avgpool2_bwd(AT* __restrict__ din, const AT* __restrict__ dout, int n, int h,
+                               int w, int c, int ho, int wo) {
+  constexpr int CE = Chunk<AT>::N;
+  int cch = c / CE;
+  int64_t total = (int64_t)n * h * w * cch;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int cc = (int)(i % cch);
+    int64_t p = i / cch;
+    int ix = (int)(p % w);
+    int iy = (int)((p / w) % h);
+    int ni = (int)(p / ((int64_t)w * h));
+    int oy = iy >> 1, ox = ix >> 1;
+    int cy = (oy * 2 + 1 < h) ? 2 : 1, cx = (ox * 2 + 1 < w) ? 2 : 1;
+    float f[CE];
+    ld_chunk<AT>(dout, (((int64_t)ni * ho + oy) * wo + ox) * cch + cc, f);
+    float r = 1.f / (cy * cx);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) f[e] *= r;
+    st_chunk<AT>(din, i, f);
+  }
+}
+
+// ------------------------------------------------------------------ per-(n,c) reductions over h*w
+// block = 256 threads = 8 chunk columns x 32 hw lanes.  MODE 0: mean x ; 1: mean silu(x) ;
+// 2: ga * sum a*b
+template <class S, class AT, int MODE>
+__global__ void k_hw_reduce(float* __restrict__ out, float* __restrict__ out_t,
+                            const AT* __restrict__ a, const AT* __restrict__ a_t,
+                            const AT* __restrict__ b, const AT* __restrict__ b_t, float mul, int hw,
+                            int c) {
+  constexpr int CE = Chunk<AT>::N;
+  int cch = c / CE;
+  int colgroups = (cch + 7) / 8;
+  int ni = blockIdx.x / colgroups;
+  int cg = blockIdx.x - ni * colgroups;
+  int col = cg * 8 + (threadIdx.x & 7);
+  int lane = threadIdx.x >> 3;  // 0..31
+  S acc[CE];
+#pragma unroll
+  for (int e = 0; e < CE; ++e) acc[e] = mk<S>(0.f, 0.f);
+  if (col < cch) {
+    for (int p = lane; p < hw; p += 32) {
+      int64_t ci = ((int64_t)ni * hw + p) * cch + col;
+      S x[CE];
+      ld_chunkS<S, AT>(a, a_t, ci, x);
+      if constexpr (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < CE; ++e) acc[e] = acc[e] + x[e];
+      } else if constexpr (MODE == 1) {
+#pragma unroll
+        for (int e = 0; e < CE; ++e) acc[e] = acc[e] + silu_(x[e]);
+      } else {
+        S y[CE];
+        ld_chunkS<S, AT>(b, b_t, ci, y);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) acc[e] = acc[e] + x[e] * y[e];
+      }
+    }
+  }
+  // reduce over the 32 hw lanes through LDS: sh[lane][colslot][e]
+  __shared__ float sh[32][8][CE * 2 + 1];
+#pragma unroll
+  for (int e = 0; e < CE; ++e) {
+    sh[lane][threadIdx.x & 7][e] = val(acc[e]);
+    sh[lane][threadIdx.x & 7][CE + e] = tan_(acc[e]);
+  }
+  __syncthreads();
+  // 8 cols * CE elems * (1 or 2) outputs
+  int nout = 8 * CE;
+  for (int o = threadIdx.x; o < nout; o += blockDim.x) {
+    int cs = o / CE, e = o - cs * CE;
+    int ccol = cg * 8 + cs;
+    if (ccol >= cch) continue;
+    float sv = 0.f, stn = 0.f;
+    for (int l = 0; l < 32; ++l) {
+      sv += sh[l][cs][e];
+      stn += sh[l][cs][CE + e];
+    }
+    int64_t oi = (int64_t)ni * c + (int64_t)ccol * CE + e;
+    if constexpr (IsDual<S>::v) out_t[oi] = stn * mul;
+    else out[oi] = sv * mul;
+  }
+}
+
+// ------------------------------------------------------------------ SE apply + residual + next pre-activation
+// X' = C3*gate*ga + SC ; A' = beta*silu(X')        (timm NormFreeBlock: out*alpha + shortcut with
+// out = attn_gain * SE(conv3(.)); ga = attn_gain*alpha; beta = next block's 1/sqrt(expected var))
+template <class S, class AT>
+__global__ void k_se_apply(const AT* __restrict__ c3, const AT* __restrict__ c3_t,
+                           const float* __restrict__ gate, const float* __restrict__ gate_t,
+                           const AT* __restrict__ sc, const AT* __restrict__ sc_t,
+                           AT* __restrict__ xo, AT* __restrict__ xo_t, AT* __restrict__ ao,
+                           AT* __restrict__ ao_t, float ga, float beta, int64_t total_chunks,
+                           int hw, int c) {
+  constexpr int CE = Chunk<AT>::N;
+  int cch = c / CE;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total_chunks;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int cc = (int)(i % cch);
+    int ni = (int)(i / ((int64_t)cch * hw));
+    S x[CE], s[CE], xo_[CE], ao_[CE];
+    ld_chunkS<S, AT>(c3, c3_t, i, x);
+    ld_chunkS<S, AT>(sc, sc_t, i, s);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+      size_t gi = (size_t)ni * c + cc * CE + e;
+      S g = ldS<S>(gate, gate_t, gi);
+      xo_[e] = x[e] * g * ga + s[e];
+      ao_[e] = silu_(xo_[e]) * beta;
+    }
+    st_chunkS<S, AT>(xo, xo_t, i, xo_);
+    if (ao || ao_t) st_chunkS<S, AT>(ao, ao_t, i, ao_);
+  }
+}
+// c3bar = xbar*gate*ga + pbar/hw
+template <class S, class AT>
+__global__ void k_se_apply_bwd(AT* __restrict__ c3bar, AT* __restrict__ c3bar_t,
+                               const AT* __restrict__ xbar, const AT* __restrict__ xbar_t,
+                               const float* __restrict__ gate, const float* __restrict__ gate_t,
+                               const float* __restrict__ pbar, const float* __restrict__ pbar_t,
+                               float ga, int64_t total_chunks, int hw, int c) {
+  constexpr int CE = Chunk<AT>::N;
+  int cch = c / CE;
+  float rhw = 1.f / hw;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total_chunks;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int cc = (int)(i % cch);
+    int ni = (int)(i / ((int64_t)cch * hw));
+    S x[CE], o[CE];
+    ld_chunkS<S, AT>(xbar, xbar_t, i, x);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+      size_t gi = (size_t)ni * c + cc * CE + e;
+      S g = ldS<S>(gate, gate_t, gi);
+      S pb = ldS<S>(pbar, pbar_t, gi);
+      o[e] = x[e] * g * ga + pb * rhw;
+    }
+    st_chunkS<S, AT>(c3bar, c3bar_t, i, o);
+  }
+}
+// cfbar = ybar/hw * dsilu(cf)
+template <class S, class AT>
+__global__ void k_final_pool_bwd(AT* __restrict__ cfbar, AT* __restrict__ cfbar_t,
+                                 const float* __restrict__ ybar, const float* __restrict__ ybar_t,
+                                 const AT* __restrict__ cf, const AT* __restrict__ cf_t,
+                                 int64_t total_chunks, int hw, int c) {
+  constexpr int CE = Chunk<AT>::N;
+  int cch = c / CE;
+  float rhw = 1.f / hw;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total_chunks;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int cc = (int)(i % cch);
+    int ni = (int)(i / ((int64_t)cch * hw));
+    S x[CE], o[CE];
+    ld_chunkS<S, AT>(cf, cf_t, i, x);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+      size_t gi = (size_t)ni * c + cc * CE + e;
+      S yb = ldS<S>(ybar, ybar_t, gi);
+      o[e] = yb * rhw * dsilu_(x[e]);
+    }
+    st_chunkS<S, AT>(cfbar, cfbar_t, i, o);
+  }
+}
+
+template <class S>
+__global__ void k_small_pointwise(int mode, float* __restrict__ out, float* __restrict__ out_t,
+                                  const float* __restrict__ a, const float* __restrict__ a_t,
+                                  const float* __restrict__ b, const float* __restrict__ b_t, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    S x = ldS<S>(a, a_t, i), y = ldS<S>(b, b_t, i);
+    S r;
+    if (mode == 0) r = x * y * (1.f - y);          // z-bar = gate-bar * gate * (1 - gate)
+    else r = val(y) > 0.f ? x : mk<S>(0.f, 0.f);   // h-bar = g * [h > 0]
+    stS<S>(out, out_t, i, r);
+  }
+}
+
+}  // namespace
+
+// ====================================================================== launchers
+template <class AT>
+void launch_img_gather_nhwc(AT* x0, const float* image, const int64_t* idx, int n, int c, int h,
+                            int w, int cpad, hipStream_t st) {
+  k_img_gather<AT><<<egrid((int64_t)n * h * w), 256, 0, st>>>(x0, image, idx, n, c, h, w, cpad);
+}
+template <class AT>
+void launch_img_scatter_grad(float* dimage, const AT* x0bar, const int64_t* idx, const float* coef,
+                             float mul, int n, int c, int h, int w, int cpad, hipStream_t st) {
+  k_img_scatter<AT><<<egrid((int64_t)n * h * w), 256, 0, st>>>(dimage, x0bar, idx, coef, mul, n, c,
+                                                               h, w, cpad);
+}
+template <class AT>
+void launch_avgpool2(AT* out, const AT* in, int n, int h, int w, int c, int stride,
+                     hipStream_t st) {
+  int ho = (h + stride - 1) / stride, wo = (w + stride - 1) / stride;
+  int64_t total = (int64_t)n * ho * wo * (c / Chunk<AT>::N);
+  k_avgpool2<AT><<<egrid(total), 256, 0, st>>>(out, in, n, h, w, c, stride, ho, wo);
+}
+template <class AT>
+void launch_avgpool2_bwd(AT* din, const AT* dout, int n, int h, int w, int c, int stride,
+                         hipStream_t st) {
+  int ho = (h + stride - 1) / stride, wo = (w + stride - 1) / stride;
+  int64_t total = (int64_t)n * h * w * (c / Chunk<AT>::N);
+  k_avgpool2_bwd<AT><<<egrid(total), 256, 0, st>>>(din, dout, n, h, w, c, ho, wo);
+}
+template <class AT>
+void launch_pool_mean(float* p, const AT* x, int n, int hw, int c, hipStream_t st) {
+  int colgroups = (c / Chunk<AT>::N + 7) / 8;
+  k_hw_reduce<float, AT, 0><<<n * colgroups, 256, 0, st>>>(p, nullptr, x, nullptr, nullptr,
+                                                           nullptr, 1.f / hw, hw, c);
+}
+template <class AT>
+void launch_se_apply(const AT* c3, const AT* c3_t, const float* gate, const float* gate_t,
+                     const AT* sc, const AT* sc_t, AT* xo, AT* xo_t, AT* ao, AT* ao_t, float ga,
+                     float beta, int n, int hw, int c, hipStream_t st) {
+  int64_t total = (int64_t)n * hw * (c / Chunk<AT>::N);
+  if (c3_t)
+    k_se_apply<Dual, AT><<<egrid(total), 256, 0, st>>>(c3, c3_t, gate, gate_t, sc, sc_t, xo, xo_t,
+                                                       ao, ao_t, ga, beta, total, hw, c);
+  else
+    k_se_apply<float, AT><<<egrid(total), 256, 0, st>>>(c3, nullptr, gate, nullptr, sc, nullptr,
+                                                        xo, nullptr, ao, nullptr, ga, beta, total,
+                                                        hw, c);
+}
+template <class AT>
+void launch_se_gate_grad(float* dgate, float* dgate_t, const AT* xbar, const AT* xbar_t,
+                         const AT* c3, const AT* c3_t, float ga, int n, int hw, int c,
+                         hipStream_t st) {
+  int colgroups = (c / Chunk<AT>::N + 7) / 8;
+  if (xbar_t)
+    k_hw_reduce<Dual, AT, 2><<<n * colgroups, 256, 0, st>>>(dgate, dgate_t, xbar, xbar_t, c3, c3_t,
+                                                            ga, hw, c);
+  else
+    k_hw_reduce<float, AT, 2><<<n * colgroups, 256, 0, st>>>(dgate, nullptr, xbar, nullptr, c3,
+                                                             nullptr, ga, hw, c);
+}
+template <class AT>
+void launch_se_apply_bwd(AT* c3bar, AT* c3bar_t, const AT* xbar, const AT* xbar_t,
+                         const float* gate, const float* gate_t, const float* pbar,
+                         const float* pbar_t, float ga, int n, int hw, int c, hipStream_t st) {
+  int64_t total = (int64_t)n * hw * (c / Chunk<AT>::N);
+  if (xbar_t)
+    k_se_apply_bwd<Dual, AT><<<egrid(total), 256, 0, st>>>(c3bar, c3bar_t, xbar, xbar_t, gate,
+                                                           gate_t, pbar, pbar_t, ga, total, hw, c);
+  else
+    k_se_apply_bwd<float, AT><<<egrid(total), 256, 0, st>>>(c3bar, nullptr, xbar, nullptr, gate,
+                                                            nullptr, pbar, nullptr, ga, total, hw,
+                                                            c);
+}
+template <class AT>
+void launch_final_pool(float* y, float* y_t, const AT* cf, const AT* cf_t, int n, int hw, int c,
+                       hipStream_t st) {
+  int colgroups = (c / Chunk<AT>::N + 7) / 8;
+  if (cf_t)
+    k_hw_reduce<Dual, AT, 1><<<n * colgroups, 256, 0, st>>>(y, y_t, cf, cf_t, nullptr, nullptr,
+                                                            1.f / hw, hw, c);
+  else
+    k_hw_reduce<float, AT, 1><<<n * colgroups, 256, 0, st>>>(y, nullptr, cf, nullptr, nullptr,
+                                                             nullptr, 1.f / hw, hw, c);
+}
+template <class AT>
+void launch_final_pool_bwd(AT* cfbar, AT* cfbar_t, const float* ybar, const float* ybar_t,
+                           const AT* cf, const AT* cf_t, int n, int hw, int c, hipStream_t st) {
+  int64_t total = (int64_t)n * hw * (c / Chunk<AT>::N);
+  if (cf_t)
+    k_final_pool_bwd<Dual, AT><<<egrid(total), 256, 0, st>>>(cfbar, cfbar_t, ybar, ybar_t, cf,
+                                                             cf_t, total, hw, c);
+  else
+    k_final_pool_bwd<float, AT><<<egrid(total), 256, 0, st>>>(cfbar, nullptr, ybar, nullptr, cf,
+                                                              nullptr, total, hw, c);
+}
+void launch_small_pointwise(int mode, float* out, float* out_t, const float* a, const float* a_t,
+                            const float* b, const float* b_t, int n, hipStream_t st) {
+  int grid = (n + 255) / 256;
+  if (out_t)
+    k_small_pointwise<Dual><<<grid, 256, 0, st>>>(mode, out, out_t, a, a_t, b, b_t, n);
+  else
+    k_small_pointwise<float><<<grid, 256, 0, st>>>(mode, out, nullptr, a, nullptr, b, nullptr, n);
+}
+
+#define INST(AT)                                                                                   \
+  template void launch_img_gather_nhwc<AT>(AT*, const float*, const int64_t*, int, int, int, int,  \
+                                           int, hipStream_t);                                      \
+  template void launch_img_scatter_grad<AT>(float*, const AT*, const int64_t*, const float*,       \
+                                            float, int, int, int, int, int, hipStream_t);          \
+  template void launch_avgpool2<AT>(AT*, const AT*, int, int, int, int, int, hipStream_t);         \
+  template void launch_avgpool2_bwd<AT>(AT*, const AT*, int, int, int, int, int, hipStream_t);     \
+  template void launch_pool_mean<AT>(float*, const AT*, int, int, int, hipStream_t);               \
+  template void launch_se_apply<AT>(const AT*, const AT*, const float*, const float*, const AT*,   \
+                                    const AT*, AT*, AT*, AT*, AT*, float, float, int, int, int,    \
+                                    hipStream_t);                                                  \
+  template void launch_se_gate_grad<AT>(float*, float*, const AT*, const AT*, const AT*,           \
+                                        const AT*, float, int, int, int, hipStream_t);             \
+  template void launch_se_apply_bwd<AT>(AT*, AT*, const AT*, const AT*, const float*,              \
+                                        const float*, const float*, const float*, float, int, int, \
+                                        int, hipStream_t);                                         \
+  template void launch_final_pool<AT>(float*, float*, const AT*, const AT*, int, int, int,         \
+                                      hipStream_t);                                                \
+  template void launch_final_pool_bwd<AT>(AT*, AT*, const float*, const float*, const AT*,         \
+                                          const AT*, int, int, int, hipStream_t);
+INST(float)
+INST(bf16)

@@ -1,0 +1,937 @@
+// Host-side engine of libmdd_hip.so: network spec + parameter table in the reference's flatten
+// order, HBM workspace plan, and the walkers that launch the gfx950 kernels for
+//   F  : student forward                                   (reference distill.py:524, 537)
+//   B  : inner gradient  d contrastive / d theta           (reference distill.py:562-567)
+//   T  : tangent (forward-over-reverse) of F and B         (what distill.py:606 differentiates)
+// plus mdd_unrolled_match: the whole outer iteration (distill.py:509-606) as an explicit tape:
+//   theta_{k+1} = theta_k - lr*g_k ;  lambda_K = 2(theta_K - theta*)/||theta_0 - theta*||^2 ;
+//   for k = K-1..0:  v = lr*lambda ; (H v, d/dX, d/ds) = R_v{grad L}(theta_k) ;
+//                    lambda -= H v ; dX -= d/dX ; dlr -= <g_k, lambda> ...
+// Activations of every step are kept in HBM (288 GB): forward stash {c, silu(c)} and backward
+// stash {a-bar, c-bar} per conv site, so the tangent pass never recomputes a primal contraction.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <type_traits>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "mdd_hip.h"
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+int mdd_set_error(hipError_t e, const char* what) {
+  char buf[512];
+  snprintf(buf, sizeof buf, "HIP error %d (%s) at %s%s", (int)e, hipGetErrorString(e), what,
+           e == hipErrorOutOfMemory ? " : out of memory" : "");
+  g_err = buf;
+  return 1000 + (int)e;
+}
+int mdd_set_error_msg(int code, const char* msg) {
+  g_err = msg;
+  return code;
+}
+#define CHECK_ARG(cond, msg) \
+  do { if (!(cond)) return mdd_set_error_msg(2, "mdd: invalid argument: " msg); } while (0)
+#define POST_LAUNCH(what) HIP_CHECK_RET(hipGetLastError())
+
+// ------------------------------------------------------------------------------------------ spec
+namespace {
+
+struct NfCfg {
+  int depths[4];
+  int channels[4];
+  int stem_chs, group_size;
+  float bottle_ratio, feat_mult, se_rd_ratio;
+  float alpha, attn_gain, eps, gamma;
+};
+int make_divisible(double v, int divisor, double round_limit = 0.9) {
+  int nv = std::max(divisor, (int)(v + divisor / 2.0) / divisor * divisor);
+  if (nv < round_limit * v) nv += divisor;
+  return nv;
+}
+bool get_cfg(const char* variant, NfCfg& c) {
+  // timm 0.6.7 nfnet.py: _nfnet_cfg(depths, feat_mult, group_size=64, bottle_ratio=0.25,
+  //   attn_kwargs=dict(rd_ratio=0.25, rd_divisor=8), act_layer='silu'); alpha 0.2, attn_gain 2.0,
+  //   std_conv_eps 1e-5, gamma = _nonlin_gamma['silu']
+  NfCfg base = {{1, 2, 6, 3}, {256, 512, 1536, 1536}, 128, 64, 0.25f, 1.5f, 0.25f,
+                0.2f, 2.0f, 1e-5f, 1.7881293296813965f};
+  if (!strcmp(variant, "nfnet_l0")) { c = base; return true; }
+  if (!strcmp(variant, "nfnet_l1")) {
+    c = base; int d[4] = {2, 4, 12, 6}; memcpy(c.depths, d, sizeof d); c.feat_mult = 2.0f; return true;
+  }
+  if (!strcmp(variant, "nfnet_tiny")) {  // build-defined miniature (tests)
+    c = base; int d[4] = {1, 2, 2, 1}; int ch[4] = {64, 128, 192, 192};
+    memcpy(c.depths, d, sizeof d); memcpy(c.channels, ch, sizeof ch);
+    c.stem_chs = 64; c.group_size = 16; return true;
+  }
+  return false;
+}
+
+struct ParamInfo { std::string name; int64_t shape[4]; int ndim; int64_t offset, numel; };
+
+struct ConvL {
+  int cin, cout, k, stride, pad, groups;
+  int hin, hout;          // square spatial dims
+  int cin_pad;            // total input channels as stored (conv1: 8)
+  int64_t off_w, off_b, off_g;
+  int64_t off_p;          // offset into packed buffers (same for wf / wt / dwf)
+  int64_t packed() const { return (int64_t)cout * k * k * (cin_pad / groups); }
+};
+struct SeL { int c, rd; int64_t off_w1, off_b1, off_w2, off_b2; };
+struct Blk {
+  int ds, c1, c2, c2b, c3;  // conv indices (ds = -1: identity shortcut)
+  SeL se;
+  int stride, cin, cout, mid, hin, hout;
+  float beta;               // pre-activation scale of THIS block's input
+};
+
+struct Arena {
+  int64_t cur = 0;
+  int64_t take(int64_t bytes) {
+    int64_t o = cur;
+    cur += (bytes + 255) / 256 * 256;
+    return o;
+  }
+};
+struct NamedBuf { std::string name; int slot; int64_t off, elems; bool f32; };
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ engine
+struct mdd_engine {
+  mdd_config cfg;
+  std::string variant;
+  virtual ~mdd_engine() {}
+  virtual int64_t workspace_bytes() const = 0;
+  virtual int bind(void* ws, int64_t bytes, hipStream_t st) = 0;
+  virtual int img_forward(bool T, int slot, const float* th, const float* th_t, const float* image,
+                          const int64_t* idx, float* feat_out, hipStream_t st) = 0;
+  virtual int img_backward(bool T, int slot, const float* th, const float* th_t, const float* ybar,
+                           const float* ybar_t, float* gout, float* dimage, const int64_t* idx,
+                           const float* coef, float mul, bool repack, hipStream_t st) = 0;
+  virtual int txt_forward(bool T, int slot, const float* th, const float* th_t, const float* text,
+                          const int64_t* idx, const float* mask, float* feat_out,
+                          hipStream_t st) = 0;
+  virtual int txt_backward(bool T, int slot, const float* th, const float* th_t, const float* ybar,
+                           const float* ybar_t, float* gout, float* dtext, const int64_t* idx,
+                           const float* coef, float mul, hipStream_t st) = 0;
+  virtual int contrastive(bool T, const float* x, const float* y, const float* x_t,
+                          const float* y_t, const float* scale_dev, float scale_const, float* loss,
+                          float* xbar, float* ybar, float* sbar, hipStream_t st) = 0;
+  virtual int unrolled_match(const mdd_iter_args* a, hipStream_t st) = 0;
+  std::vector<ParamInfo> pimg, ptxt;
+  int64_t P_img = 0, P_txt = 0;
+  int feat = 0;
+  std::vector<NamedBuf> names;
+};
+
+namespace {
+
+template <class AT>
+struct Eng : mdd_engine {
+  NfCfg nf;
+  int N, S, Dt, K;
+  std::vector<ConvL> convs;
+  std::vector<Blk> blks;
+  int stem[4], fin;
+  std::vector<int> xh, xc;  // stream spatial dim / channels: X[b], b = 0..nb
+  int64_t packed_total = 0;
+  int total_rows = 0;
+  std::vector<WsDesc> descs;
+  // text head offsets
+  int64_t t_pw, t_pb, t_fw, t_fb, t_lw, t_lb;
+
+  // ---------------- workspace plan (byte offsets), resolved to pointers at bind()
+  struct BlockActs {
+    AT *P, *SC, *C1, *A1, *C2, *A2, *C2b, *A2b, *C3;
+    float *p, *h, *gate;
+    AT *C3B, *A2bB, *C2bB, *A2B, *C2B, *A1B, *C1B, *AinB;
+    float *gateB, *zB, *hB, *pB;
+  };
+  struct ActSet {
+    AT* X0;
+    AT *Cs[3], *As[3];
+    std::vector<AT*> X, A, XB;  // stream, pre-activated stream, stream grads
+    std::vector<BlockActs> blk;
+    AT *CF, *CFB;
+    AT *AsB[3], *CsB[3];
+    AT* X0B;
+    float *y, *yB;              // image features / their grads
+    float* dwf;                 // grad wrt standardised weights (fp32, packed layout)
+    // text head
+    float *tx, *tp, *tg, *tf, *tr, *ty;
+    float *tyB, *trB, *tfB, *tgB, *tpB, *txB;
+  };
+  std::vector<ActSet> sets;  // per slot
+  ActSet tn;                 // tangent set
+  int64_t ws_bytes = 0;
+  char* base = nullptr;
+  Arena arena;
+  // persistent / scratch
+  int64_t o_descs; WsDesc* d_descs = nullptr;
+  AT *wf = nullptr, *wt = nullptr, *wf_t = nullptr, *wt_t = nullptr;
+  AT *dsS = nullptr, *dsF = nullptr;       // downsample dgrad scratch (pooled / full res)
+  float *se_tmp = nullptr, *se_tmp_t = nullptr, *ln_stats = nullptr;
+  float* lossw = nullptr;
+  // unrolled-match state
+  std::vector<float*> thI, thT, gI, gT;    // theta_k (k=1..K), g_k
+  float *lamI, *lamT, *nuI, *nuT, *hI, *hT;
+  float *fx_t, *fy_t, *xbar, *ybar, *xbar_t, *ybar_t, *sbar, *sbar_t;
+  double* dsc;                              // [0..3] sqdist, [4],[5] dlr
+  std::vector<std::pair<void**, int64_t>> fix;  // pointer fix-ups (address of pointer, offset)
+
+  template <class T> void plan(T** slot_ptr, int64_t elems, const char* name, int slot) {
+    int64_t off = arena.take(elems * (int64_t)sizeof(T));
+    fix.push_back({(void**)slot_ptr, off});
+    if (name) names.push_back({name, slot, off, elems, sizeof(T) == 4 && std::is_same<T, float>::value});
+  }
+
+  // ------------------------------------------------------------------ construction
+  int build(const mdd_config& c) {
+    cfg = c; variant = c.variant; cfg.variant = variant.c_str();
+    N = c.batch; S = c.image_size; Dt = c.d_txt; K = c.syn_steps;
+    CHECK_ARG(get_cfg(c.variant, nf), "unknown variant");
+    CHECK_ARG(S % 32 == 0 && S >= 32, "image_size must be a multiple of 32");
+    CHECK_ARG(N >= 2 && N <= 1024, "batch must be in [2,1024]");
+    CHECK_ARG(K >= 1 && K <= 64, "syn_steps must be in [1,64]");
+    CHECK_ARG(Dt >= 1, "d_txt");
+    int64_t off = 0;
+    auto add_param = [&](std::vector<ParamInfo>& tab, const std::string& name,
+                         std::initializer_list<int64_t> shp) {
+      ParamInfo p; p.name = name; p.ndim = (int)shp.size(); p.numel = 1;
+      int i = 0; for (auto s : shp) { p.shape[i++] = s; p.numel *= s; }
+      for (; i < 4; ++i) p.shape[i] = 1;
+      p.offset = off; off += p.numel; tab.push_back(p);
+      return p.offset;
+    };
+    auto add_conv = [&](const std::string& name, int cin, int cout, int k, int stride, int groups,
+                        int hin) {
+      ConvL L; L.cin = cin; L.cout = cout; L.k = k; L.stride = stride; L.groups = groups;
+      L.pad = ((stride - 1) + (k - 1)) / 2;
+      L.hin = hin; L.hout = (hin + 2 * L.pad - k) / stride + 1;
+      L.cin_pad = cin < 8 ? 8 : cin;
+      L.off_w = add_param(pimg, name + ".weight", {cout, cin / groups, k, k});
+      L.off_b = add_param(pimg, name + ".bias", {cout});
+      L.off_g = add_param(pimg, name + ".gain", {cout, 1, 1, 1});
+      L.off_p = packed_total; packed_total += L.packed();
+      convs.push_back(L);
+      return (int)convs.size() - 1;
+    };
+    // stem 'deep_quad': 3x3 convs, channels (sc/8, sc/4, sc/2, sc), strides (2,1,1,2)
+    int sc = nf.stem_chs, chs[4] = {sc / 8, sc / 4, sc / 2, sc}, strides[4] = {2, 1, 1, 2};
+    int prev = 3, h = S;
+    for (int i = 0; i < 4; ++i) {
+      stem[i] = add_conv("model.stem.conv" + std::to_string(i + 1), prev, chs[i], 3, strides[i], 1, h);
+      h = convs[stem[i]].hout; prev = chs[i];
+    }
+    xh.push_back(h); xc.push_back(prev);
+    double expected_var = 1.0;
+    for (int si = 0; si < 4; ++si) {
+      for (int bi = 0; bi < nf.depths[si]; ++bi) {
+        Blk B; std::string pre = "model.stages." + std::to_string(si) + "." + std::to_string(bi);
+        int stride = (bi == 0 && si > 0) ? 2 : 1;
+        int out = make_divisible(nf.channels[si], 8);
+        int mid = make_divisible(out * nf.bottle_ratio, 8);
+        int groups = nf.group_size ? mid / nf.group_size : 1;
+        if (nf.group_size && nf.group_size % 8 == 0) mid = nf.group_size * groups;
+        B.stride = stride; B.cin = prev; B.cout = out; B.mid = mid; B.hin = h;
+        B.beta = (float)(1.0 / std::sqrt(expected_var));
+        int hout = stride == 2 ? (h + 1) / 2 : h;
+        B.ds = -1;
+        if (prev != out || stride != 1) B.ds = add_conv(pre + ".downsample.conv", prev, out, 1, 1, 1, hout);
+        B.c1 = add_conv(pre + ".conv1", prev, mid, 1, 1, 1, h);
+        B.c2 = add_conv(pre + ".conv2", mid, mid, 3, stride, groups, h);
+        B.c2b = add_conv(pre + ".conv2b", mid, mid, 3, 1, groups, hout);
+        B.c3 = add_conv(pre + ".conv3", mid, out, 1, 1, 1, hout);
+        CHECK_ARG(convs[B.c2].hout == hout, "internal: spatial plan");
+        B.se.c = out; B.se.rd = make_divisible(out * nf.se_rd_ratio, 8, 0.0);
+        B.se.off_w1 = add_param(pimg, pre + ".attn_last.fc1.weight", {B.se.rd, out, 1, 1});
+        B.se.off_b1 = add_param(pimg, pre + ".attn_last.fc1.bias", {B.se.rd});
+        B.se.off_w2 = add_param(pimg, pre + ".attn_last.fc2.weight", {out, B.se.rd, 1, 1});
+        B.se.off_b2 = add_param(pimg, pre + ".attn_last.fc2.bias", {out});
+        B.hout = hout;
+        blks.push_back(B);
+        if (bi == 0) expected_var = 1.0;
+        expected_var += (double)nf.alpha * nf.alpha;
+        prev = out; h = hout;
+        xh.push_back(h); xc.push_back(prev);
+      }
+    }
+    feat = (int)(nf.channels[3] * nf.feat_mult);
+    fin = add_conv("model.final_conv", prev, feat, 1, 1, 1, h);
+    P_img = off;
+    CHECK_ARG(feat <= 4096, "feature dim > 4096 unsupported by the contrastive head kernel");
+    // text head (reference networks.py:625-646)
+    off = 0;
+    t_pw = add_param(ptxt, "projection.weight", {feat, Dt});
+    t_pb = add_param(ptxt, "projection.bias", {feat});
+    t_fw = add_param(ptxt, "fc.weight", {feat, feat});
+    t_fb = add_param(ptxt, "fc.bias", {feat});
+    t_lw = add_param(ptxt, "layer_norm.weight", {feat});
+    t_lb = add_param(ptxt, "layer_norm.bias", {feat});
+    P_txt = off;
+    // weight-standardisation descriptors
+    int row = 0;
+    for (auto& L : convs) {
+      WsDesc d; d.off_w = L.off_w; d.off_b = L.off_b; d.off_g = L.off_g;
+      d.off_wf = L.off_p; d.off_wt = L.off_p;
+      d.cout = L.cout; d.cin_g = L.cin / L.groups; d.ksq = L.k * L.k; d.groups = L.groups;
+      d.cin_pad_g = L.cin_pad / L.groups; d.cout_g = L.cout / L.groups;
+      d.scale = nf.gamma / std::sqrt((float)(d.cin_g * d.ksq)); d.eps = nf.eps;
+      d.row_start = row; row += L.cout;
+      descs.push_back(d);
+      int ce = 16 / (int)sizeof(AT);
+      CHECK_ARG(d.cin_pad_g % ce == 0 && d.cout_g % ce == 0, "channel counts must be multiples of the 16-byte chunk");
+    }
+    total_rows = row;
+    plan_workspace();
+    return 0;
+  }
+
+  void plan_set(ActSet& s, int slot) {
+    int nb = (int)blks.size();
+    auto nm = [&](const std::string& n) { return n; };
+    int64_t n = N;
+    plan(&s.X0, n * S * S * 8, "X0", slot);
+    for (int i = 0; i < 3; ++i) {
+      const ConvL& L = convs[stem[i]];
+      int64_t e = n * L.hout * L.hout * L.cout;
+      plan(&s.Cs[i], e, ("stem.C" + std::to_string(i)).c_str(), slot);
+      plan(&s.As[i], e, ("stem.A" + std::to_string(i)).c_str(), slot);
+      plan(&s.AsB[i], e, ("stem.AB" + std::to_string(i)).c_str(), slot);
+      plan(&s.CsB[i], e, ("stem.CB" + std::to_string(i)).c_str(), slot);
+    }
+    plan(&s.X0B, n * S * S * 8, "X0B", slot);
+    s.X.resize(nb + 1); s.A.resize(nb + 1); s.XB.resize(nb + 1); s.blk.resize(nb);
+    for (int b = 0; b <= nb; ++b) {
+      int64_t e = n * xh[b] * xh[b] * xc[b];
+      plan(&s.X[b], e, ("X" + std::to_string(b)).c_str(), slot);
+      plan(&s.XB[b], e, ("XB" + std::to_string(b)).c_str(), slot);
+      if (b < nb) plan(&s.A[b], e, ("A" + std::to_string(b)).c_str(), slot); else s.A[b] = nullptr;
+    }
+    for (int b = 0; b < nb; ++b) {
+      const Blk& B = blks[b]; BlockActs& a = s.blk[b];
+      std::string p = "b" + std::to_string(b) + ".";
+      int64_t ein = n * B.hin * B.hin, eout = n * B.hout * B.hout;
+      a.P = nullptr; a.SC = nullptr;
+      if (B.ds >= 0 && B.stride == 2) plan(&a.P, eout * B.cin, (p + "P").c_str(), slot);
+      if (B.ds >= 0) plan(&a.SC, eout * B.cout, (p + "SC").c_str(), slot);
+      plan(&a.C1, ein * B.mid, (p + "C1").c_str(), slot);   plan(&a.A1, ein * B.mid, (p + "A1").c_str(), slot);
+      plan(&a.C2, eout * B.mid, (p + "C2").c_str(), slot);  plan(&a.A2, eout * B.mid, (p + "A2").c_str(), slot);
+      plan(&a.C2b, eout * B.mid, (p + "C2b").c_str(), slot); plan(&a.A2b, eout * B.mid, (p + "A2b").c_str(), slot);
+      plan(&a.C3, eout * B.cout, (p + "C3").c_str(), slot);
+      plan(&a.p, n * B.se.c, (p + "p").c_str(), slot); plan(&a.h, n * B.se.rd, (p + "h").c_str(), slot);
+      plan(&a.gate, n * B.se.c, (p + "gate").c_str(), slot);
+      plan(&a.C3B, eout * B.cout, (p + "C3B").c_str(), slot);
+      plan(&a.A2bB, eout * B.mid, (p + "A2bB").c_str(), slot); plan(&a.C2bB, eout * B.mid, (p + "C2bB").c_str(), slot);
+      plan(&a.A2B, eout * B.mid, (p + "A2B").c_str(), slot);   plan(&a.C2B, eout * B.mid, (p + "C2B").c_str(), slot);
+      plan(&a.A1B, ein * B.mid, (p + "A1B").c_str(), slot);    plan(&a.C1B, ein * B.mid, (p + "C1B").c_str(), slot);
+      plan(&a.AinB, ein * B.cin, (p + "AinB").c_str(), slot);
+      plan(&a.gateB, n * B.se.c, (p + "gateB").c_str(), slot); plan(&a.zB, n * B.se.c, (p + "zB").c_str(), slot);
+      plan(&a.hB, n * B.se.rd, (p + "hB").c_str(), slot);      plan(&a.pB, n * B.se.c, (p + "pB").c_str(), slot);
+    }
+    int64_t ef = n * xh[nb] * xh[nb] * feat;
+    plan(&s.CF, ef, "CF", slot); plan(&s.CFB, ef, "CFB", slot);
+    plan(&s.y, n * feat, "y", slot); plan(&s.yB, n * feat, "yB", slot);
+    plan(&s.dwf, packed_total, "dwf", slot);
+    plan(&s.tx, n * Dt, "tx", slot); plan(&s.tp, n * feat, "tp", slot); plan(&s.tg, n * feat, "tg", slot);
+    plan(&s.tf, n * feat, "tf", slot); plan(&s.tr, n * feat, "tr", slot); plan(&s.ty, n * feat, "ty", slot);
+    plan(&s.tyB, n * feat, "tyB", slot); plan(&s.trB, n * feat, "trB", slot); plan(&s.tfB, n * feat, "tfB", slot);
+    plan(&s.tgB, n * feat, "tgB", slot); plan(&s.tpB, n * feat, "tpB", slot); plan(&s.txB, n * Dt, "txB", slot);
+    (void)nm;
+  }
+
+  void plan_workspace() {
+    arena = Arena(); fix.clear(); names.clear();
+    o_descs = arena.take((int64_t)descs.size() * sizeof(WsDesc));
+    plan(&wf, packed_total, "wf", -2); plan(&wt, packed_total, "wt", -2);
+    plan(&wf_t, packed_total, "wf_t", -2); plan(&wt_t, packed_total, "wt_t", -2);
+    int64_t dsmax = 0, dfmax = 0, semax = 0;
+    for (auto& B : blks) {
+      if (B.ds >= 0) {
+        dsmax = std::max(dsmax, (int64_t)N * B.hout * B.hout * B.cin);
+        dfmax = std::max(dfmax, (int64_t)N * B.hin * B.hin * B.cin);
+      }
+      semax = std::max(semax, (int64_t)N * std::max(B.se.rd, B.se.c));
+    }
+    plan(&dsS, dsmax, "dsS", -2); plan(&dsF, dfmax, "dsF", -2);
+    plan(&se_tmp, semax, nullptr, -2); plan(&se_tmp_t, semax, nullptr, -2);
+    plan(&ln_stats, (int64_t)N * 4, nullptr, -2);
+    plan(&lossw, loss_work_floats(N, feat), nullptr, -2);
+    sets.resize(K);
+    for (int k = 0; k < K; ++k) plan_set(sets[k], k);
+    plan_set(tn, -1);
+    thI.assign(K + 1, nullptr); thT.assign(K + 1, nullptr); gI.assign(K, nullptr); gT.assign(K, nullptr);
+    for (int k = 1; k <= K; ++k) { plan(&thI[k], P_img, nullptr, -2); plan(&thT[k], P_txt, nullptr, -2); }
+    for (int k = 0; k < K; ++k) { plan(&gI[k], P_img, nullptr, -2); plan(&gT[k], P_txt, nullptr, -2); }
+    plan(&lamI, P_img, nullptr, -2); plan(&lamT, P_txt, nullptr, -2);
+    plan(&nuI, P_img, nullptr, -2); plan(&nuT, P_txt, nullptr, -2);
+    plan(&hI, P_img, nullptr, -2); plan(&hT, P_txt, nullptr, -2);
+    int64_t nf_ = (int64_t)N * feat;
+    plan(&fx_t, nf_, nullptr, -2); plan(&fy_t, nf_, nullptr, -2);
+    plan(&xbar, nf_, nullptr, -2); plan(&ybar, nf_, nullptr, -2);
+    plan(&xbar_t, nf_, nullptr, -2); plan(&ybar_t, nf_, nullptr, -2);
+    plan(&sbar, 64, nullptr, -2); plan(&sbar_t, 64, nullptr, -2);
+    plan(&dsc, 16, nullptr, -2);
+    ws_bytes = arena.cur;
+  }
+  int64_t workspace_bytes() const override { return ws_bytes; }
+
+  int bind(void* ws, int64_t bytes, hipStream_t st) override {
+    CHECK_ARG(ws != nullptr, "workspace is null");
+    CHECK_ARG(bytes >= ws_bytes, "workspace too small");
+    CHECK_ARG(((uintptr_t)ws & 255) == 0, "workspace must be 256-byte aligned");
+    base = (char*)ws;
+    for (auto& f : fix) *f.first = (void*)(base + f.second);
+    d_descs = (WsDesc*)(base + o_descs);
+    HIP_CHECK_RET(hipMemcpyAsync(d_descs, descs.data(), descs.size() * sizeof(WsDesc),
+                                 hipMemcpyHostToDevice, st));
+    // packed weight buffers carry zero padding (conv1: 3 -> 8 input channels) that is never rewritten
+    HIP_CHECK_RET(hipMemsetAsync(wf, 0, packed_total * sizeof(AT), st));
+    HIP_CHECK_RET(hipMemsetAsync(wt, 0, packed_total * sizeof(AT), st));
+    HIP_CHECK_RET(hipMemsetAsync(wf_t, 0, packed_total * sizeof(AT), st));
+    HIP_CHECK_RET(hipMemsetAsync(wt_t, 0, packed_total * sizeof(AT), st));
+    HIP_CHECK_RET(hipStreamSynchronize(st));  // descs.data() is host memory
+    return 0;
+  }
+
+  // ------------------------------------------------------------------ geometry helpers
+  ConvGeom gfwd(const ConvL& L) const {
+    ConvGeom g; g.nimg = N; g.ha = L.hin; g.wa = L.hin; g.ca_tot = L.cin_pad;
+    g.ho = L.hout; g.wo = L.hout; g.co_tot = L.cout; g.kc = L.cin_pad / L.groups;
+    g.nc = L.cout / L.groups; g.groups = L.groups; g.k = L.k; g.stride = L.stride; g.pad = L.pad;
+    g.transposed = 0; return g;
+  }
+  ConvGeom gdgrad(const ConvL& L) const {
+    ConvGeom g; g.nimg = N; g.ha = L.hout; g.wa = L.hout; g.ca_tot = L.cout;
+    g.ho = L.hin; g.wo = L.hin; g.co_tot = L.cin_pad; g.kc = L.cout / L.groups;
+    g.nc = L.cin_pad / L.groups; g.groups = L.groups; g.k = L.k; g.stride = L.stride; g.pad = L.pad;
+    g.transposed = 1; return g;
+  }
+
+  // c = conv(in) + bias ; C <- c ; A <- beta*silu(c).   T: tangent of the same (primal from stash)
+  void conv_fwd(bool T, const ConvL& L, const AT* in, const AT* in_t, AT* C, AT* C_t, AT* A,
+                AT* A_t, float beta, const float* th, const float* th_t, hipStream_t st) {
+    ConvGeom g = gfwd(L);
+    ConvEpi e; memset(&e, 0, sizeof e);
+    e.beta = beta;
+    if (!T) {
+      e.mode = EPI_FWD; e.bias = th + L.off_b; e.out_raw = C; e.out_act = A;
+      launch_conv_gemm<AT>(g, in, wf + L.off_p, nullptr, nullptr, e, st);
+    } else {
+      e.mode = EPI_FWD_T; e.bias_t = th_t + L.off_b; e.out_raw = C_t; e.out_act = A_t; e.c = C;
+      if (in_t) launch_conv_gemm<AT>(g, in_t, wf + L.off_p, in, wf_t + L.off_p, e, st);
+      else launch_conv_gemm<AT>(g, in, wf_t + L.off_p, nullptr, nullptr, e, st);
+    }
+  }
+  // weight + bias gradient of conv L (dy = grad wrt its raw output, x = its input)
+  void conv_bwd_w(bool T, const ConvL& L, const AT* dy, const AT* dy_t, const AT* x, const AT* x_t,
+                  float* dwf_, float* dwf_t_, float* gout, hipStream_t st) {
+    ConvGeom g = gfwd(L);
+    if (!T) launch_conv_wgrad<AT>(g, dy, x, nullptr, nullptr, dwf_ + L.off_p, gout + L.off_b, st);
+    else launch_conv_wgrad<AT>(g, dy_t, x, x_t ? dy : nullptr, x_t, dwf_t_ + L.off_p, gout + L.off_b, st);
+  }
+  // data gradient of conv L with fused epilogue
+  void conv_bwd_d(bool T, const ConvL& L, const AT* dy, const AT* dy_t, ConvEpi e, hipStream_t st) {
+    ConvGeom g = gdgrad(L);
+    if (!T) launch_conv_gemm<AT>(g, dy, wt + L.off_p, nullptr, nullptr, e, st);
+    else launch_conv_gemm<AT>(g, dy_t, wt + L.off_p, dy, wt_t + L.off_p, e, st);
+  }
+  ConvEpi epi_act(bool T, AT* raw, AT* act, AT* act_t, const AT* c, const AT* c_t, float beta,
+                  const AT* add1, const AT* add2) {
+    ConvEpi e; memset(&e, 0, sizeof e);
+    e.beta = beta; e.add1 = add1; e.add2 = add2; e.c = c;
+    if (!T) { e.mode = EPI_BWD; e.out_raw = raw; e.out_act = act; }
+    else { e.mode = EPI_BWD_T; e.out_raw = nullptr; e.out_act = act_t; e.c_t = c_t; e.abar = raw; }
+    return e;
+  }
+  ConvEpi epi_lin(AT* raw, const AT* add1) {
+    ConvEpi e; memset(&e, 0, sizeof e);
+    e.mode = EPI_BWD_LIN; e.out_raw = raw; e.add1 = add1; e.beta = 1.f; return e;
+  }
+
+  // ------------------------------------------------------------------ image encoder: F / T-fwd
+  int img_forward(bool T, int slot, const float* th, const float* th_t, const float* image,
+                  const int64_t* idx, float* feat_out, hipStream_t st) override {
+    CHECK_ARG(base, "workspace not bound");
+    CHECK_ARG(slot >= 0 && slot < K, "slot out of range");
+    ActSet& P = sets[slot]; ActSet& Q = tn;
+    int nb = (int)blks.size();
+    launch_ws_forward<AT>(d_descs, (int)descs.size(), total_rows, th, T ? th_t : nullptr, wf, wt,
+                          wf_t, wt_t, st);
+    if (!T) launch_img_gather_nhwc<AT>(P.X0, image, idx, N, 3, S, S, 8, st);
+    const AT* in = P.X0; const AT* in_t = nullptr;
+    for (int i = 0; i < 4; ++i) {
+      bool last = i == 3;
+      AT* C = last ? P.X[0] : P.Cs[i];  AT* C_t = last ? Q.X[0] : Q.Cs[i];
+      AT* A = last ? P.A[0] : P.As[i];  AT* A_t = last ? Q.A[0] : Q.As[i];
+      conv_fwd(T, convs[stem[i]], in, in_t, C, C_t, A, A_t, last ? blks[0].beta : 1.f, th, th_t, st);
+      in = A; in_t = A_t;
+    }
+    const float ga = nf.attn_gain * nf.alpha;
+    for (int b = 0; b < nb; ++b) {
+      const Blk& B = blks[b]; BlockActs& pa = P.blk[b]; BlockActs& qa = Q.blk[b];
+      const AT *x = P.X[b], *x_t = Q.X[b], *a = P.A[b], *a_t = Q.A[b];
+      const AT *sc = x, *sc_t = x_t;
+      if (B.ds >= 0) {
+        const AT *din = a, *din_t = a_t;
+        if (B.stride == 2) {
+          launch_avgpool2<AT>(T ? qa.P : pa.P, T ? a_t : a, N, B.hin, B.hin, B.cin, 2, st);
+          din = pa.P; din_t = qa.P;
+        }
+        conv_fwd(T, convs[B.ds], din, din_t, pa.SC, qa.SC, nullptr, nullptr, 1.f, th, th_t, st);
+        sc = pa.SC; sc_t = qa.SC;
+      }
+      conv_fwd(T, convs[B.c1], a, a_t, pa.C1, qa.C1, pa.A1, qa.A1, 1.f, th, th_t, st);
+      conv_fwd(T, convs[B.c2], pa.A1, qa.A1, pa.C2, qa.C2, pa.A2, qa.A2, 1.f, th, th_t, st);
+      conv_fwd(T, convs[B.c2b], pa.A2, qa.A2, pa.C2b, qa.C2b, pa.A2b, qa.A2b, 1.f, th, th_t, st);
+      conv_fwd(T, convs[B.c3], pa.A2b, qa.A2b, pa.C3, qa.C3, nullptr, nullptr, 1.f, th, th_t, st);
+      int hw = B.hout * B.hout, c = B.se.c, rd = B.se.rd;
+      launch_pool_mean<AT>(T ? qa.p : pa.p, T ? qa.C3 : pa.C3, N, hw, c, st);
+      launch_linear_fwd(pa.h, T ? qa.h : nullptr, pa.p, T ? qa.p : nullptr, th + B.se.off_w1,
+                        T ? th_t + B.se.off_w1 : nullptr, th + B.se.off_b1,
+                        T ? th_t + B.se.off_b1 : nullptr, N, c, rd, 1, st);
+      launch_linear_fwd(pa.gate, T ? qa.gate : nullptr, pa.h, T ? qa.h : nullptr, th + B.se.off_w2,
+                        T ? th_t + B.se.off_w2 : nullptr, th + B.se.off_b2,
+                        T ? th_t + B.se.off_b2 : nullptr, N, rd, c, 2, st);
+      bool lastb = b == nb - 1;
+      launch_se_apply<AT>(pa.C3, T ? qa.C3 : nullptr, pa.gate, T ? qa.gate : nullptr, sc,
+                          T ? sc_t : nullptr, P.X[b + 1], T ? Q.X[b + 1] : nullptr,
+                          lastb ? nullptr : P.A[b + 1], (T && !lastb) ? Q.A[b + 1] : nullptr, ga,
+                          lastb ? 1.f : blks[b + 1].beta, N, hw, c, st);
+    }
+    conv_fwd(T, convs[fin], P.X[nb], Q.X[nb], P.CF, Q.CF, nullptr, nullptr, 1.f, th, th_t, st);
+    int hwf = xh[nb] * xh[nb];
+    launch_final_pool<AT>(P.y, T ? feat_out : nullptr, P.CF, T ? Q.CF : nullptr, N, hwf, feat, st);
+    if (!T && feat_out && feat_out != P.y)
+      HIP_CHECK_RET(hipMemcpyAsync(feat_out, P.y, (size_t)N * feat * 4, hipMemcpyDeviceToDevice, st));
+    POST_LAUNCH("img_forward");
+    return 0;
+  }
+
+  // ------------------------------------------------------------------ image encoder: B / T-bwd
+  int img_backward(bool T, int slot, const float* th, const float* th_t, const float* ybar_in,
+                   const float* ybar_t_in, float* gout, float* dimage, const int64_t* idx,
+                   const float* coef, float mul, bool repack, hipStream_t st) override {
+    CHECK_ARG(base, "workspace not bound");
+    CHECK_ARG(slot >= 0 && slot < K, "slot out of range");
+    ActSet& P = sets[slot]; ActSet& Q = tn;
+    int nb = (int)blks.size();
+    if (repack)
+      launch_ws_forward<AT>(d_descs, (int)descs.size(), total_rows, th, T ? th_t : nullptr, wf, wt,
+                            wf_t, wt_t, st);
+    float* dw = P.dwf; float* dw_t = Q.dwf;
+    HIP_CHECK_RET(hipMemsetAsync(T ? dw_t : dw, 0, packed_total * 4, st));
+    HIP_CHECK_RET(hipMemsetAsync(gout, 0, P_img * 4, st));
+    if (!T && ybar_in != P.yB)
+      HIP_CHECK_RET(hipMemcpyAsync(P.yB, ybar_in, (size_t)N * feat * 4, hipMemcpyDeviceToDevice, st));
+    const float ga = nf.attn_gain * nf.alpha;
+    int hwf = xh[nb] * xh[nb];
+    launch_final_pool_bwd<AT>(P.CFB, T ? Q.CFB : nullptr, P.yB, T ? ybar_t_in : nullptr, P.CF,
+                              T ? Q.CF : nullptr, N, hwf, feat, st);
+    conv_bwd_w(T, convs[fin], P.CFB, Q.CFB, P.X[nb], Q.X[nb], dw, dw_t, gout, st);
+    conv_bwd_d(T, convs[fin], P.CFB, Q.CFB, epi_lin(T ? Q.XB[nb] : P.XB[nb], nullptr), st);
+    for (int b = nb - 1; b >= 0; --b) {
+      const Blk& B = blks[b]; BlockActs& pa = P.blk[b]; BlockActs& qa = Q.blk[b];
+      const AT *xb = P.XB[b + 1], *xb_t = Q.XB[b + 1];
+      int hw = B.hout * B.hout, c = B.se.c, rd = B.se.rd;
+      // squeeze-excite backward
+      launch_se_gate_grad<AT>(pa.gateB, T ? qa.gateB : nullptr, xb, T ? xb_t : nullptr, pa.C3,
+                              T ? qa.C3 : nullptr, ga, N, hw, c, st);
+      launch_small_pointwise(0, pa.zB, T ? qa.zB : nullptr, pa.gateB, T ? qa.gateB : nullptr,
+                             pa.gate, T ? qa.gate : nullptr, N * c, st);
+      launch_linear_wgrad(gout + B.se.off_w2, gout + B.se.off_b2, pa.zB, T ? qa.zB : nullptr, pa.h,
+                          T ? qa.h : nullptr, N, rd, c, st);
+      launch_linear_dgrad(se_tmp, T ? se_tmp_t : nullptr, pa.zB, T ? qa.zB : nullptr,
+                          th + B.se.off_w2, T ? th_t + B.se.off_w2 : nullptr, N, rd, c, st);
+      launch_small_pointwise(1, pa.hB, T ? qa.hB : nullptr, se_tmp, T ? se_tmp_t : nullptr, pa.h,
+                             T ? qa.h : nullptr, N * rd, st);
+      launch_linear_wgrad(gout + B.se.off_w1, gout + B.se.off_b1, pa.hB, T ? qa.hB : nullptr, pa.p,
+                          T ? qa.p : nullptr, N, c, rd, st);
+      launch_linear_dgrad(pa.pB, T ? qa.pB : nullptr, pa.hB, T ? qa.hB : nullptr, th + B.se.off_w1,
+                          T ? th_t + B.se.off_w1 : nullptr, N, c, rd, st);
+      launch_se_apply_bwd<AT>(pa.C3B, T ? qa.C3B : nullptr, xb, T ? xb_t : nullptr, pa.gate,
+                              T ? qa.gate : nullptr, pa.pB, T ? qa.pB : nullptr, ga, N, hw, c, st);
+      // residual branch
+      conv_bwd_w(T, convs[B.c3], pa.C3B, qa.C3B, pa.A2b, qa.A2b, dw, dw_t, gout, st);
+      conv_bwd_d(T, convs[B.c3], pa.C3B, qa.C3B,
+                 epi_act(T, pa.A2bB, pa.C2bB, qa.C2bB, pa.C2b, qa.C2b, 1.f, nullptr, nullptr), st);
+      conv_bwd_w(T, convs[B.c2b], pa.C2bB, qa.C2bB, pa.A2, qa.A2, dw, dw_t, gout, st);
+      conv_bwd_d(T, convs[B.c2b], pa.C2bB, qa.C2bB,
+                 epi_act(T, pa.A2B, pa.C2B, qa.C2B, pa.C2, qa.C2, 1.f, nullptr, nullptr), st);
+      conv_bwd_w(T, convs[B.c2], pa.C2B, qa.C2B, pa.A1, qa.A1, dw, dw_t, gout, st);
+      conv_bwd_d(T, convs[B.c2], pa.C2B, qa.C2B,
+                 epi_act(T, pa.A1B, pa.C1B, qa.C1B, pa.C1, qa.C1, 1.f, nullptr, nullptr), st);
+      conv_bwd_w(T, convs[B.c1], pa.C1B, qa.C1B, P.A[b], Q.A[b], dw, dw_t, gout, st);
+      // shortcut branch
+      const AT* add1 = nullptr;
+      if (B.ds >= 0) {
+        const AT* dsin = B.stride == 2 ? pa.P : P.A[b];
+        const AT* dsin_t = B.stride == 2 ? qa.P : Q.A[b];
+        conv_bwd_w(T, convs[B.ds], xb, xb_t, dsin, dsin_t, dw, dw_t, gout, st);
+        conv_bwd_d(T, convs[B.ds], xb, xb_t, epi_lin(dsS, nullptr), st);
+        if (B.stride == 2) {
+          launch_avgpool2_bwd<AT>(dsF, dsS, N, B.hin, B.hin, B.cin, 2, st);
+          add1 = dsF;
+        } else {
+          add1 = dsS;
+        }
+      }
+      // conv1 dgrad + pre-activation chain rule + identity shortcut:  XB[b] = beta*silu'(X[b])*Abar (+ XB[b+1])
+      conv_bwd_d(T, convs[B.c1], pa.C1B, qa.C1B,
+                 epi_act(T, pa.AinB, P.XB[b], Q.XB[b], P.X[b], Q.X[b], B.beta, add1,
+                         B.ds >= 0 ? nullptr : (T ? xb_t : xb)), st);
+    }
+    // stem (conv4 output is the raw stream X[0]; its grad is XB[0])
+    conv_bwd_w(T, convs[stem[3]], P.XB[0], Q.XB[0], P.As[2], Q.As[2], dw, dw_t, gout, st);
+    conv_bwd_d(T, convs[stem[3]], P.XB[0], Q.XB[0],
+               epi_act(T, P.AsB[2], P.CsB[2], Q.CsB[2], P.Cs[2], Q.Cs[2], 1.f, nullptr, nullptr), st);
+    conv_bwd_w(T, convs[stem[2]], P.CsB[2], Q.CsB[2], P.As[1], Q.As[1], dw, dw_t, gout, st);
+    conv_bwd_d(T, convs[stem[2]], P.CsB[2], Q.CsB[2],
+               epi_act(T, P.AsB[1], P.CsB[1], Q.CsB[1], P.Cs[1], Q.Cs[1], 1.f, nullptr, nullptr), st);
+    conv_bwd_w(T, convs[stem[1]], P.CsB[1], Q.CsB[1], P.As[0], Q.As[0], dw, dw_t, gout, st);
+    conv_bwd_d(T, convs[stem[1]], P.CsB[1], Q.CsB[1],
+               epi_act(T, P.AsB[0], P.CsB[0], Q.CsB[0], P.Cs[0], Q.Cs[0], 1.f, nullptr, nullptr), st);
+    conv_bwd_w(T, convs[stem[0]], P.CsB[0], Q.CsB[0], P.X0, nullptr, dw, dw_t, gout, st);
+    if (dimage) {
+      AT* x0b = T ? Q.X0B : P.X0B;
+      conv_bwd_d(T, convs[stem[0]], P.CsB[0], Q.CsB[0], epi_lin(x0b, nullptr), st);
+      launch_img_scatter_grad<AT>(dimage, x0b, idx, coef, mul, N, 3, S, S, 8, st);
+    }
+    launch_ws_backward(d_descs, (int)descs.size(), total_rows, th, T ? th_t : nullptr, dw,
+                       T ? dw_t : nullptr, gout, st);
+    POST_LAUNCH("img_backward");
+    return 0;
+  }
+
+  // ------------------------------------------------------------------ text projection head
+  int txt_forward(bool T, int slot, const float* th, const float* th_t, const float* text,
+                  const int64_t* idx, const float* mask, float* feat_out, hipStream_t st) override {
+    CHECK_ARG(base, "workspace not bound");
+    CHECK_ARG(slot >= 0 && slot < K, "slot out of range");
+    ActSet& P = sets[slot]; ActSet& Q = tn;
+    if (!T) launch_gather_rows(P.tx, text, idx, N, Dt, st);
+    auto tt = [&](int64_t o) { return T ? th_t + o : nullptr; };
+    launch_linear_fwd(P.tp, T ? Q.tp : nullptr, P.tx, nullptr, th + t_pw, tt(t_pw), th + t_pb,
+                      tt(t_pb), N, Dt, feat, 0, st);
+    launch_gelu(P.tg, T ? Q.tg : nullptr, P.tp, T ? Q.tp : nullptr, (int64_t)N * feat, st);
+    launch_linear_fwd(P.tf, T ? Q.tf : nullptr, P.tg, T ? Q.tg : nullptr, th + t_fw, tt(t_fw),
+                      th + t_fb, tt(t_fb), N, feat, feat, 0, st);
+    // the dropout mask of this slot is kept for the backward / tangent passes
+    if (!T) slot_mask_[slot] = mask;
+    launch_ln_fwd(P.ty, T ? feat_out : nullptr, P.tr, T ? Q.tr : nullptr, P.tf, T ? Q.tf : nullptr,
+                  slot_mask_[slot], P.tp, T ? Q.tp : nullptr, th + t_lw, tt(t_lw), th + t_lb,
+                  tt(t_lb), N, feat, 1e-5f, st);
+    if (!T && feat_out && feat_out != P.ty)
+      HIP_CHECK_RET(hipMemcpyAsync(feat_out, P.ty, (size_t)N * feat * 4, hipMemcpyDeviceToDevice, st));
+    POST_LAUNCH("txt_forward");
+    return 0;
+  }
+  std::vector<const float*> slot_mask_ = std::vector<const float*>(64, nullptr);
+
+  int txt_backward(bool T, int slot, const float* th, const float* th_t, const float* ybar_in,
+                   const float* ybar_t_in, float* gout, float* dtext, const int64_t* idx,
+                   const float* coef, float mul, hipStream_t st) override {
+    CHECK_ARG(base, "workspace not bound");
+    CHECK_ARG(slot >= 0 && slot < K, "slot out of range");
+    ActSet& P = sets[slot]; ActSet& Q = tn;
+    auto tt = [&](int64_t o) { return T ? th_t + o : nullptr; };
+    if (!T && ybar_in != P.tyB)
+      HIP_CHECK_RET(hipMemcpyAsync(P.tyB, ybar_in, (size_t)N * feat * 4, hipMemcpyDeviceToDevice, st));
+    launch_ln_bwd(P.trB, T ? Q.trB : nullptr, P.tfB, T ? Q.tfB : nullptr, gout + t_lw, gout + t_lb,
+                  ln_stats, P.tyB, T ? ybar_t_in : nullptr, P.tr, T ? Q.tr : nullptr,
+                  slot_mask_[slot], th + t_lw, tt(t_lw), N, feat, 1e-5f, st);
+    launch_linear_wgrad(gout + t_fw, gout + t_fb, P.tfB, T ? Q.tfB : nullptr, P.tg,
+                        T ? Q.tg : nullptr, N, feat, feat, st);
+    launch_linear_dgrad(P.tgB, T ? Q.tgB : nullptr, P.tfB, T ? Q.tfB : nullptr, th + t_fw, tt(t_fw),
+                        N, feat, feat, st);
+    launch_gelu_bwd(P.tpB, T ? Q.tpB : nullptr, P.trB, T ? Q.trB : nullptr, P.tgB,
+                    T ? Q.tgB : nullptr, P.tp, T ? Q.tp : nullptr, (int64_t)N * feat, st);
+    launch_linear_wgrad(gout + t_pw, gout + t_pb, P.tpB, T ? Q.tpB : nullptr, P.tx, nullptr, N, Dt,
+                        feat, st);
+    if (dtext) {
+      float* xb = T ? Q.txB : P.txB;
+      launch_linear_dgrad(P.txB, T ? Q.txB : nullptr, P.tpB, T ? Q.tpB : nullptr, th + t_pw,
+                          tt(t_pw), N, Dt, feat, st);
+      launch_scatter_rows_axpy(dtext, xb, idx, coef, mul, N, Dt, st);
+    }
+    POST_LAUNCH("txt_backward");
+    return 0;
+  }
+
+  int contrastive(bool T, const float* x, const float* y, const float* x_t, const float* y_t,
+                  const float* scale_dev, float scale_const, float* loss, float* xb, float* yb,
+                  float* sb, hipStream_t st) override {
+    CHECK_ARG(base, "workspace not bound");
+    LossWork w = loss_work_carve(lossw, N, feat);
+    if (!T) launch_contrastive(w, loss, xb, yb, sb, nullptr, nullptr, nullptr, x, y, nullptr,
+                               nullptr, scale_dev, scale_const, N, feat, st);
+    else launch_contrastive(w, nullptr, nullptr, nullptr, nullptr, xb, yb, sb, x, y, x_t, y_t,
+                            scale_dev, scale_const, N, feat, st);
+    POST_LAUNCH("contrastive");
+    return 0;
+  }
+
+  // ------------------------------------------------------------------ whole outer iteration
+  int unrolled_match(const mdd_iter_args* a, hipStream_t st) override {
+    CHECK_ARG(base, "workspace not bound");
+    CHECK_ARG(a->syn_steps >= 1 && a->syn_steps <= K, "syn_steps exceeds the engine's slots");
+    const int Ks = a->syn_steps;
+    const float* scale_dev = a->use_lr_as_scale ? a->lr_img : nullptr;
+    const int64_t nfeat = (int64_t)N * feat;
+    int rc;
+    std::vector<const float*> tI(Ks + 1), tT(Ks + 1);
+    tI[0] = a->theta0_img; tT[0] = a->theta0_txt;
+    for (int k = 1; k <= Ks; ++k) { tI[k] = thI[k]; tT[k] = thT[k]; }
+    HIP_CHECK_RET(hipMemsetAsync(dsc, 0, 16 * sizeof(double), st));
+    // ---- unrolled student training (distill.py:509-583)
+    for (int k = 0; k < Ks; ++k) {
+      const int64_t* idx = a->perms ? a->perms + (int64_t)k * N : nullptr;
+      const float* mask = a->drop_masks ? a->drop_masks + (int64_t)k * nfeat : nullptr;
+      if ((rc = img_forward(false, k, tI[k], nullptr, a->image_syn, idx, nullptr, st))) return rc;
+      if ((rc = txt_forward(false, k, tT[k], nullptr, a->text_syn, idx, mask, nullptr, st))) return rc;
+      if ((rc = contrastive(false, sets[k].y, sets[k].ty, nullptr, nullptr, scale_dev,
+                            a->logit_scale_const, a->losses + 3 + k, sets[k].yB, sets[k].tyB, sbar, st)))
+        return rc;
+      if ((rc = img_backward(false, k, tI[k], nullptr, sets[k].yB, nullptr, gI[k], nullptr, nullptr,
+                             nullptr, 0.f, false, st))) return rc;
+      if ((rc = txt_backward(false, k, tT[k], nullptr, sets[k].tyB, nullptr, gT[k], nullptr, nullptr,
+                             nullptr, 0.f, st))) return rc;
+      launch_axpy_out(thI[k + 1], tI[k], gI[k], a->lr_img, -1.f, P_img, st);
+      launch_axpy_out(thT[k + 1], tT[k], gT[k], a->lr_txt, -1.f, P_txt, st);
+    }
+    // ---- trajectory-matching loss (distill.py:584-598)
+    launch_sqdist(tI[Ks], a->target_img, dsc + 0, P_img, st);
+    launch_sqdist(a->theta0_img, a->target_img, dsc + 1, P_img, st);
+    launch_sqdist(tT[Ks], a->target_txt, dsc + 2, P_txt, st);
+    launch_sqdist(a->theta0_txt, a->target_txt, dsc + 3, P_txt, st);
+    launch_match_finalize(dsc, a->losses, st);
+    // ---- outer backward (distill.py:606) as an explicit reverse sweep
+    launch_lambda_init(lamI, tI[Ks], a->target_img, dsc + 1, P_img, st);
+    launch_lambda_init(lamT, tT[Ks], a->target_txt, dsc + 3, P_txt, st);
+    HIP_CHECK_RET(hipMemsetAsync(a->grad_image_syn, 0, (size_t)cfg.num_queries * 3 * S * S * 4, st));
+    HIP_CHECK_RET(hipMemsetAsync(a->grad_text_syn, 0, (size_t)cfg.num_queries * Dt * 4, st));
+    for (int k = Ks - 1; k >= 0; --k) {
+      const int64_t* idx = a->perms ? a->perms + (int64_t)k * N : nullptr;
+      launch_dot(gI[k], lamI, dsc + 4, -1.0, P_img, st);   // d/d lr_img  -= <g_k, lambda>
+      launch_dot(gT[k], lamT, dsc + 5, -1.0, P_txt, st);
+      launch_scale_out(nuI, lamI, a->lr_img, 1.f, P_img, st);  // direction v = lr * lambda
+      launch_scale_out(nuT, lamT, a->lr_txt, 1.f, P_txt, st);
+      if ((rc = img_forward(true, k, tI[k], nuI, nullptr, nullptr, fx_t, st))) return rc;
+      if ((rc = txt_forward(true, k, tT[k], nuT, nullptr, nullptr, nullptr, fy_t, st))) return rc;
+      if ((rc = contrastive(true, sets[k].y, sets[k].ty, fx_t, fy_t, scale_dev, a->logit_scale_const,
+                            nullptr, xbar_t, ybar_t, sbar_t, st))) return rc;
+      if ((rc = img_backward(true, k, tI[k], nuI, nullptr, xbar_t, hI, a->grad_image_syn, idx, nullptr,
+                             -1.f, false, st))) return rc;
+      if ((rc = txt_backward(true, k, tT[k], nuT, nullptr, ybar_t, hT, a->grad_text_syn, idx, nullptr,
+                             -1.f, st))) return rc;
+      if (a->use_lr_as_scale) launch_accum_f2d(dsc + 4, sbar_t, -1.0, st);
+      launch_sub_inplace(lamI, hI, P_img, st);
+      launch_sub_inplace(lamT, hT, P_txt, st);
+    }
+    launch_d2f(a->grad_lr, dsc + 4, 1.f, 0, 2, st);
+    POST_LAUNCH("unrolled_match");
+    return 0;
+  }
+};
+
+}  // namespace
+
+// ========================================================================================== C ABI
+extern "C" {
+
+const char* mdd_last_error(void) { return g_err.c_str(); }
+int mdd_version(void) { return 1; }
+
+int mdd_engine_create(const mdd_config* cfg, mdd_engine** out) {
+  CHECK_ARG(cfg && out && cfg->variant, "null config");
+  *out = nullptr;
+  if (cfg->dtype == MDD_DTYPE_F32) {
+    auto* e = new Eng<float>();
+    int rc = e->build(*cfg);
+    if (rc) { delete e; return rc; }
+    *out = e;
+  } else if (cfg->dtype == MDD_DTYPE_BF16) {
+    auto* e = new Eng<bf16>();
+    int rc = e->build(*cfg);
+    if (rc) { delete e; return rc; }
+    *out = e;
+  } else {
+    return mdd_set_error_msg(2, "mdd: invalid argument: dtype");
+  }
+  return 0;
+}
+void mdd_engine_destroy(mdd_engine* e) { delete e; }
+int64_t mdd_engine_workspace_bytes(const mdd_engine* e) { return e ? e->workspace_bytes() : -1; }
+int mdd_engine_bind_workspace(mdd_engine* e, void* ws, int64_t bytes, void* stream) {
+  CHECK_ARG(e, "null engine");
+  return e->bind(ws, bytes, (hipStream_t)stream);
+}
+int64_t mdd_engine_param_numel(const mdd_engine* e, int which) {
+  return !e ? -1 : (which == 0 ? e->P_img : e->P_txt);
+}
+int mdd_engine_param_count(const mdd_engine* e, int which) {
+  return !e ? -1 : (int)(which == 0 ? e->pimg.size() : e->ptxt.size());
+}
+int mdd_engine_param_info(const mdd_engine* e, int which, int index, char* name, int name_cap,
+                          int64_t* shape4, int* ndim, int64_t* offset) {
+  CHECK_ARG(e, "null engine");
+  const auto& tab = which == 0 ? e->pimg : e->ptxt;
+  CHECK_ARG(index >= 0 && index < (int)tab.size(), "param index");
+  const ParamInfo& p = tab[index];
+  if (name && name_cap > 0) { strncpy(name, p.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  if (shape4) memcpy(shape4, p.shape, sizeof p.shape);
+  if (ndim) *ndim = p.ndim;
+  if (offset) *offset = p.offset;
+  return 0;
+}
+int mdd_engine_feature_dim(const mdd_engine* e) { return e ? e->feat : -1; }
+int mdd_engine_find_buffer(const mdd_engine* e, const char* name, int slot, int64_t* byte_offset,
+                           int64_t* elems, int* is_float32) {
+  CHECK_ARG(e && name, "null");
+  for (const auto& b : e->names)
+    if (b.slot == slot && b.name == name) {
+      if (byte_offset) *byte_offset = b.off;
+      if (elems) *elems = b.elems;
+      if (is_float32) *is_float32 = b.f32 ? 1 : 0;
+      return 0;
+    }
+  return mdd_set_error_msg(3, "mdd: buffer not found");
+}
+
+int mdd_img_forward(mdd_engine* e, int slot, const float* th, const float* image,
+                    const int64_t* idx, float* feat_out, void* stream) {
+  CHECK_ARG(e && th && image, "null pointer");
+  return e->img_forward(false, slot, th, nullptr, image, idx, feat_out, (hipStream_t)stream);
+}
+int mdd_img_backward(mdd_engine* e, int slot, const float* th, const float* fb, float* gout,
+                     void* stream) {
+  CHECK_ARG(e && th && fb && gout, "null pointer");
+  return e->img_backward(false, slot, th, nullptr, fb, nullptr, gout, nullptr, nullptr, nullptr, 0.f,
+                         true, (hipStream_t)stream);
+}
+int mdd_img_tangent_forward(mdd_engine* e, int slot, const float* th, const float* thd,
+                            float* fdot, void* stream) {
+  CHECK_ARG(e && th && thd && fdot, "null pointer");
+  return e->img_forward(true, slot, th, thd, nullptr, nullptr, fdot, (hipStream_t)stream);
+}
+int mdd_img_tangent_backward(mdd_engine* e, int slot, const float* th, const float* thd,
+                             const float* fbd, float* hout, float* dimage, const int64_t* idx,
+                             const float* coef, float mul, void* stream) {
+  CHECK_ARG(e && th && thd && fbd && hout, "null pointer");
+  return e->img_backward(true, slot, th, thd, nullptr, fbd, hout, dimage, idx, coef, mul, true,
+                         (hipStream_t)stream);
+}
+int mdd_txt_forward(mdd_engine* e, int slot, const float* th, const float* text,
+                    const int64_t* idx, const float* mask, float* feat_out, void* stream) {
+  CHECK_ARG(e && th && text, "null pointer");
+  return e->txt_forward(false, slot, th, nullptr, text, idx, mask, feat_out, (hipStream_t)stream);
+}
+int mdd_txt_backward(mdd_engine* e, int slot, const float* th, const float* fb, float* gout,
+                     void* stream) {
+  CHECK_ARG(e && th && fb && gout, "null pointer");
+  return e->txt_backward(false, slot, th, nullptr, fb, nullptr, gout, nullptr, nullptr, nullptr, 0.f,
+                         (hipStream_t)stream);
+}
+int mdd_txt_tangent_forward(mdd_engine* e, int slot, const float* th, const float* thd,
+                            float* fdot, void* stream) {
+  CHECK_ARG(e && th && thd && fdot, "null pointer");
+  return e->txt_forward(true, slot, th, thd, nullptr, nullptr, nullptr, fdot, (hipStream_t)stream);
+}
+int mdd_txt_tangent_backward(mdd_engine* e, int slot, const float* th, const float* thd,
+                             const float* fbd, float* hout, float* dtext, const int64_t* idx,
+                             const float* coef, float mul, void* stream) {
+  CHECK_ARG(e && th && thd && fbd && hout, "null pointer");
+  return e->txt_backward(true, slot, th, thd, nullptr, fbd, hout, dtext, idx, coef, mul,
+                         (hipStream_t)stream);
+}
+int mdd_contrastive(mdd_engine* e, const float* x, const float* y, const float* scale_dev,
+                    float scale_const, float* loss, float* xbar, float* ybar, float* sbar,
+                    void* stream) {
+  CHECK_ARG(e && x && y && loss && xbar && ybar && sbar, "null pointer");
+  return e->contrastive(false, x, y, nullptr, nullptr, scale_dev, scale_const, loss, xbar, ybar,
+                        sbar, (hipStream_t)stream);
+}
+int mdd_contrastive_tangent(mdd_engine* e, const float* x, const float* y, const float* xd,
+                            const float* yd, const float* scale_dev, float scale_const,
+                            float* xbd, float* ybd, float* sbd, void* stream) {
+  CHECK_ARG(e && x && y && xd && yd && xbd && ybd && sbd, "null pointer");
+  return e->contrastive(true, x, y, xd, yd, scale_dev, scale_const, nullptr, xbd, ybd, sbd,
+                        (hipStream_t)stream);
+}
+int mdd_flat_axpy(float* out, const float* x, const float* g, const float* lr, float sign,
+                  int64_t n, void* stream) {
+  CHECK_ARG(out && x && g && lr && n >= 0, "null pointer");
+  launch_axpy_out(out, x, g, lr, sign, n, (hipStream_t)stream);
+  POST_LAUNCH("axpy");
+  return 0;
+}
+int mdd_flat_sqdist(const float* a, const float* b, double* out, int64_t n, void* stream) {
+  CHECK_ARG(a && b && out && n >= 0, "null pointer");
+  launch_sqdist(a, b, out, n, (hipStream_t)stream);
+  POST_LAUNCH("sqdist");
+  return 0;
+}
+int mdd_flat_sgd_momentum(float* p, const float* g, float* buf, float lr, float mom, int first,
+                          int64_t n, void* stream) {
+  CHECK_ARG(p && g && buf && n >= 0, "null pointer");
+  launch_sgd_momentum(p, g, buf, lr, mom, first, n, (hipStream_t)stream);
+  POST_LAUNCH("sgd");
+  return 0;
+}
+int mdd_unrolled_match(mdd_engine* e, const mdd_iter_args* a, void* stream) {
+  CHECK_ARG(e && a, "null pointer");
+  CHECK_ARG(a->image_syn && a->text_syn && a->lr_img && a->lr_txt && a->theta0_img &&
+                a->theta0_txt && a->target_img && a->target_txt && a->grad_image_syn &&
+                a->grad_text_syn && a->grad_lr && a->losses, "null pointer in mdd_iter_args");
+  return e->unrolled_match(a, (hipStream_t)stream);
+}
+
+static ConvGeom op_geom(int transposed, int nimg, int hin, int win, int cin, int cout, int k,
+                        int stride, int pad, int groups) {
+  int hout = (hin + 2 * pad - k) / stride + 1, wout = (win + 2 * pad - k) / stride + 1;
+  ConvGeom g;
+  g.nimg = nimg; g.groups = groups; g.k = k; g.stride = stride; g.pad = pad; g.transposed = transposed;
+  if (!transposed) {
+    g.ha = hin; g.wa = win; g.ca_tot = cin; g.ho = hout; g.wo = wout; g.co_tot = cout;
+    g.kc = cin / groups; g.nc = cout / groups;
+  } else {
+    g.ha = hout; g.wa = wout; g.ca_tot = cout; g.ho = hin; g.wo = win; g.co_tot = cin;
+    g.kc = cout / groups; g.nc = cin / groups;
+  }
+  return g;
+}
+int mdd_op_conv2d(int dtype, int transposed, int nimg, int hin, int win, int cin, int cout, int k,
+                  int stride, int pad, int groups, const void* a, const void* w, const float* bias,
+                  void* out, void* stream) {
+  CHECK_ARG(a && w && out, "null pointer");
+  CHECK_ARG(stride == 1 || stride == 2, "stride must be 1 or 2");
+  ConvGeom g = op_geom(transposed, nimg, hin, win, cin, cout, k, stride, pad, groups);
+  ConvEpi e; memset(&e, 0, sizeof e);
+  e.mode = transposed ? EPI_BWD_LIN : EPI_FWD; e.bias = bias; e.out_raw = out; e.beta = 1.f;
+  if (dtype == MDD_DTYPE_F32)
+    launch_conv_gemm<float>(g, (const float*)a, (const float*)w, nullptr, nullptr, e, (hipStream_t)stream);
+  else
+    launch_conv_gemm<bf16>(g, (const bf16*)a, (const bf16*)w, nullptr, nullptr, e, (hipStream_t)stream);
+  POST_LAUNCH("op_conv2d");
+  return 0;
+}
+int mdd_op_conv2d_wgrad(int dtype, int nimg, int hin, int win, int cin, int cout, int k, int stride,
+                        int pad, int groups, const void* dy, const void* x, float* dw, float* db,
+                        void* stream) {
+  CHECK_ARG(dy && x && dw, "null pointer");
+  ConvGeom g = op_geom(0, nimg, hin, win, cin, cout, k, stride, pad, groups);
+  if (dtype == MDD_DTYPE_F32)
+    launch_conv_wgrad<float>(g, (const float*)dy, (const float*)x, nullptr, nullptr, dw, db, (hipStream_t)stream);
+  else
+    launch_conv_wgrad<bf16>(g, (const bf16*)dy, (const bf16*)x, nullptr, nullptr, dw, db, (hipStream_t)stream);
+  POST_LAUNCH("op_conv2d_wgrad");
+  return 0;
+}
+
+}  // extern "C"

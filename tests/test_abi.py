@@ -1,0 +1,80 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/mdd_hip.h declares,
+and its host-only queries (parameter table, workspace plan) agree with the oracle.  No compute."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _lib():
+    from multimodal_dataset_distillation_amd import _lib, build_ext
+    if not os.path.exists(_lib.LIB_PATH):
+        build_ext.build(verbose=False)
+    return _lib
+
+
+def test_header_symbols_all_exported():
+    lib = _lib().load()
+    hdr = open(os.path.join(ROOT, "include", "mdd_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mdd_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    from multimodal_dataset_distillation_amd._lib import SIGNATURES
+    assert declared == set(SIGNATURES), declared ^ set(SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+@pytest.mark.parametrize("variant,expect", [("nfnet_l0", 32769488), ("nfnet_tiny", None)])
+def test_param_table_matches_oracle_and_reference_counts(variant, expect):
+    from multimodal_dataset_distillation_amd.engine import UnrollEngine
+    from oracle import distill_ref as dr, nfnet_ref as nr
+    d_txt = 768 if variant == "nfnet_l0" else 32
+    eng = UnrollEngine(variant, batch=10, image_size=224 if variant == "nfnet_l0" else 64,
+                       d_txt=d_txt, syn_steps=2, dtype="f32", bind=False)
+    fi = dr.FlatModule(nr.ImageEncoder(variant))
+    ft = dr.FlatModule(dr.ProjectionHead(d_txt, eng.feature_dim))
+    assert eng.feature_dim == fi.module.model.num_features
+    if expect:
+        assert eng.P_img == expect            # 32,769,488 (35.07 M with timm's head)
+        assert eng.P_txt == 7087104           # networks.py:625-646 with 768 -> 2304
+        assert eng.feature_dim == 2304        # networks.py:811
+    for which, fm in (("img", fi), ("txt", ft)):
+        tab = eng.param_table(which)
+        assert [t[0] for t in tab] == fm.names
+        assert [tuple(t[1]) for t in tab] == fm.shapes
+        assert [t[2] for t in tab] == np.cumsum([0] + fm.numels[:-1]).tolist()
+    assert eng.workspace_bytes > 0
+    eng.close()
+
+
+def test_invalid_arguments_fail_loudly():
+    from multimodal_dataset_distillation_amd.engine import UnrollEngine
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        UnrollEngine("no_such_net", bind=False)
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        UnrollEngine("nfnet_tiny", image_size=50, bind=False)
+
+
+def test_product_path_needs_gpu_no_cpu_fallback():
+    import torch
+    from multimodal_dataset_distillation_amd.engine import UnrollEngine
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        UnrollEngine("nfnet_tiny", batch=4, image_size=64, d_txt=32, syn_steps=1, dtype="f32")
+
+
+def test_c2_workspace_fits_hbm():
+    """BASELINE config 2 (N=100, syn_steps=8, bf16) must fit one MI355X (288 GB HBM3E)."""
+    from multimodal_dataset_distillation_amd.engine import UnrollEngine
+    eng = UnrollEngine("nfnet_l0", batch=100, image_size=224, d_txt=768, syn_steps=8, dtype="bf16",
+                       bind=False)
+    gib = eng.workspace_bytes / 2**30
+    print("C2 workspace GiB:", gib)
+    assert gib < 240
+    eng.close()

@@ -1,0 +1,121 @@
+"""GPU parity of the single-op C-ABI entry points (implicit-GEMM conv forward / dgrad / wgrad)
+against torch CPU fp32 convolution.  f32 mode (exact-fp32 MFMA) must agree to 1e-4 relative
+(norm-wise; summation order differs), bf16 mode to 2e-2 (operands rounded to bf16)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # nimg, h, cin, cout, k, stride, groups          (pad = ((s-1)+(k-1))//2 as timm)
+    (2, 16, 8, 16, 3, 2, 1),      # stem conv1 shape class (cin padded to 8, N=16)
+    (2, 16, 16, 32, 3, 1, 1),     # stem conv2 (K=144 not a multiple of the K tile)
+    (3, 12, 64, 64, 3, 1, 1),     # group width 64, one group
+    (2, 12, 128, 128, 3, 2, 2),   # grouped, strided
+    (2, 14, 384, 384, 3, 1, 6),   # stage-2 grouped 3x3
+    (3, 14, 256, 64, 1, 1, 1),    # 1x1 reduce
+    (3, 7, 96, 160, 1, 1, 1),     # 1x1, ragged M (147 rows), N=160 -> partial N tile
+    (2, 9, 32, 48, 3, 2, 1),      # odd spatial size with stride 2
+    (5, 1, 64, 40, 1, 1, 1),      # M = 5 (linear-layer-like)
+]
+
+
+def pack_fwd(w, groups):
+    cout, cin_g, k, _ = w.shape
+    return w.permute(0, 2, 3, 1).reshape(cout, k * k, cin_g).contiguous()
+
+
+def pack_dgrad(w, groups):
+    cout, cin_g, k, _ = w.shape
+    cout_g = cout // groups
+    return (w.view(groups, cout_g, cin_g, k, k).permute(0, 2, 3, 4, 1)
+            .reshape(groups, cin_g, k * k, cout_g).contiguous())
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_ops(case, dtype, report):
+    from multimodal_dataset_distillation_amd import _lib
+    lib = _lib.load()
+    nimg, h, cin, cout, k, stride, groups = case
+    pad = ((stride - 1) + (k - 1)) // 2
+    torch.manual_seed(hash(case) % 1000)
+    x = torch.randn(nimg, cin, h, h)
+    w = torch.randn(cout, cin // groups, k, k) / (cin // groups * k * k) ** 0.5
+    b = torch.randn(cout)
+    tdt = torch.float32 if dtype == "f32" else torch.bfloat16
+    code = 0 if dtype == "f32" else 1
+    tol = 1e-4 if dtype == "f32" else 2e-2
+    if dtype == "bf16":  # reference on the bf16-rounded operands: isolates accumulation error
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    x.requires_grad_(True), w.requires_grad_(True)
+    y = F.conv2d(x, w, b, stride, pad, 1, groups)
+    dy = torch.randn_like(y)
+    if dtype == "bf16":
+        dy = dy.bfloat16().float()
+    gx, gw = torch.autograd.grad(y, [x, w], dy)
+    gb = dy.sum((0, 2, 3))
+    ho = y.shape[2]
+    dev = "cuda"
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    xd = nhwc(x.detach()).to(dev, tdt)
+    wf = pack_fwd(w.detach(), groups).to(dev, tdt)
+    wt = pack_dgrad(w.detach(), groups).to(dev, tdt)
+    bd = b.to(dev)
+    # forward
+    yo = torch.full((nimg, ho, ho, cout), float("nan"), device=dev, dtype=tdt)
+    _lib.check(lib.mdd_op_conv2d(code, 0, nimg, h, h, cin, cout, k, stride, pad, groups, P(xd), P(wf),
+                                 P(bd), P(yo), st))
+    e_f = rel_err(yo.float().cpu().permute(0, 3, 1, 2), y)
+    # dgrad
+    dyd = nhwc(dy).to(dev, tdt)
+    dxo = torch.full((nimg, h, h, cin), float("nan"), device=dev, dtype=tdt)
+    _lib.check(lib.mdd_op_conv2d(code, 1, nimg, h, h, cin, cout, k, stride, pad, groups, P(dyd), P(wt),
+                                 None, P(dxo), st))
+    e_d = rel_err(dxo.float().cpu().permute(0, 3, 1, 2), gx)
+    # wgrad (+ bias grad)
+    dwo = torch.zeros(cout, k * k, cin // groups, device=dev)
+    dbo = torch.zeros(cout, device=dev)
+    _lib.check(lib.mdd_op_conv2d_wgrad(code, nimg, h, h, cin, cout, k, stride, pad, groups, P(dyd),
+                                       P(xd), P(dwo), P(dbo), st))
+    torch.cuda.synchronize()
+    gw_o = dwo.cpu().view(cout, k * k, cin // groups).permute(0, 2, 1).reshape(cout, cin // groups, k, k)
+    e_w = rel_err(gw_o, gw)
+    e_b = rel_err(dbo.cpu(), gb)
+    report(f"conv_ops {dtype} {case}: fwd {e_f:.2e} dgrad {e_d:.2e} wgrad {e_w:.2e} bias {e_b:.2e}")
+    assert e_f < tol and e_d < tol and e_w < tol and e_b < tol
+
+
+def test_flat_ops(report):
+    from multimodal_dataset_distillation_amd import _lib
+    lib = _lib.load()
+    dev = "cuda"
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    for n in (1, 3, 4, 1027, 1 << 20, (1 << 22) + 3):
+        torch.manual_seed(n)
+        x, g = torch.randn(n), torch.randn(n)
+        lr = torch.tensor([0.37])
+        out = torch.empty(n, device=dev)
+        _lib.check(lib.mdd_flat_axpy(P(out), P(x.to(dev)), P(g.to(dev)), P(lr.to(dev)), -1.0, n, st))
+        assert torch.equal(out.cpu(), x + (-1.0 * 0.37) * g) or rel_err(out, x - 0.37 * g) < 1e-7
+        acc = torch.zeros(1, dtype=torch.float64, device=dev)
+        _lib.check(lib.mdd_flat_sqdist(P(x.to(dev)), P(g.to(dev)), P(acc), n, st))
+        ref = ((x.double() - g.double()) ** 2).sum()
+        assert abs(acc.item() - ref.item()) <= 1e-6 * ref.item() + 1e-12
+        p, buf = x.clone().to(dev), torch.zeros(n, device=dev)
+        _lib.check(lib.mdd_flat_sgd_momentum(P(p), P(g.to(dev)), P(buf), 1000.0, 0.5, 1, n, st))
+        _lib.check(lib.mdd_flat_sgd_momentum(P(p), P(g.to(dev)), P(buf), 1000.0, 0.5, 0, n, st))
+        ref_p = x - 1000.0 * g - 1000.0 * (0.5 * g + g)
+        assert rel_err(p, ref_p) < 1e-6
+    report("flat_ops ok")
