@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: distillation iterations/sec (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one outer distillation iteration on one expert trajectory (reference
+distill.py:466-613 minus eval/logging/student rebuild): syn_steps unrolled student steps
+(NFNet-l0 + text projection forward, contrastive loss, inner gradient, theta update), the
+normalised trajectory-matching loss, the outer gradient w.r.t. (image_syn, text_syn, lr_img, lr_txt)
+and the three SGD-momentum updates.  Workload at N=1: BASELINE config 2 (100 synthetic pairs,
+syn_steps=8, NFNet-l0 + 768-d text, 224x224, bf16), synthetic inputs + synthetic expert snapshots
+resident in HBM.  Multi-GPU (SURVEY 8e mode A): one expert replica per rank, full synthetic set
+replicated, ONE RCCL all-reduce of [d image_syn | d text_syn | d lr] per step, identical SGD step on
+every rank; value = expert-iterations/sec over all ranks (weak scaling).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (variant, pairs, syn_steps, image, d_txt)
+    "c2": ("nfnet_l0", 100, 8, 224, 768),     # BASELINE.json configs[1] -- the metric's config
+    "c1": ("nfnet_l0", 10, 2, 224, 768),      # configs[0] (reference's CPU-runnable case)
+    "tiny": ("nfnet_tiny", 4, 2, 64, 32),     # plumbing
+}
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+KIND_NAMES = ["conv_gemm<128x32>", "conv_gemm<256x64>", "conv_gemm<128x128>", "conv_wgrad<64x128>"]
+
+
+def algorithmic_flops_per_iter(n, syn_steps):
+    """9 contractions of forward size per conv/linear per step."""
+    macs_fwd = n * (4.2419e9 + 7.08e6) + n * n * 2304
+    return syn_steps * 9 * 2 * macs_fwd
+
+
+def cpu_baseline(workload, seconds_budget=30.0):
+    """The oracle (oracle/distill_ref.py, torch CPU fp32 autograd) timed on the host cores on a
+    bounded sample of the same workload, extrapolated linearly in pairs*syn_steps."""
+    from oracle import distill_ref as dr, nfnet_ref as nr
+    variant, n, K, size, d_txt = WORKLOADS[workload]
+    sn, sK = (min(n, 4), 1) if variant == "nfnet_l0" else (n, K)
+    torch.manual_seed(0)
+    enc = nr.ImageEncoder(variant)
+    nr.randomize_like_trained(enc, 1)
+    fi = dr.FlatModule(enc)
+    ft = dr.FlatModule(dr.ProjectionHead(d_txt, enc.model.num_features))
+    img, txt = dr.synthetic_inputs(sn, size, d_txt, seed=3)
+    img.requires_grad_(True), txt.requires_grad_(True)
+    lri, lrt = torch.tensor(0.1, requires_grad=True), torch.tensor(0.1, requires_grad=True)
+    th0i, th0t = fi.flat_param(), ft.flat_param()
+    tgi, tgt = th0i + 1e-3 * torch.randn_like(th0i), th0t + 1e-3 * torch.randn_like(th0t)
+    perms = [torch.randperm(sn) for _ in range(sK)]
+    t0 = time.time()
+    reps = 0
+    while True:
+        grand, _ = dr.unrolled_match(fi, ft, img, txt, lri, lrt, th0i, th0t, tgi, tgt, perms)
+        dr.outer_grads(grand, img, txt, lri, lrt)
+        reps += 1
+        if time.time() - t0 > seconds_budget * 0.5 or reps >= 3:
+            break
+    dt = (time.time() - t0) / reps
+    scale = (n * K) / float(sn * sK)
+    return {"value": 1.0 / (dt * scale), "unit": "iters/sec", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "oracle/distill_ref.py torch-CPU fp32, %d pairs x %d syn_step(s) of %s @%d, "
+                      "%.1f s per sample iteration, scaled x%.0f (pairs*syn_steps) to the full workload"
+                      % (sn, sK, variant, size, dt, scale)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from multimodal_dataset_distillation_amd import _lib
+    from multimodal_dataset_distillation_amd.engine import UnrollEngine
+    from multimodal_dataset_distillation_amd.networks import synthetic_expert_params
+
+    variant, n, K, size, d_txt = WORKLOADS[args.workload]
+    eng = UnrollEngine(variant, batch=n, num_queries=n, image_size=size, d_txt=d_txt, syn_steps=K,
+                       dtype=args.dtype, device=dev)
+    lib = _lib.load()
+
+    # ---- synthetic inputs: identical on every rank
+    g = torch.Generator().manual_seed(0)
+    mean = torch.tensor([-0.0626, -0.0221, 0.0680]).view(1, 3, 1, 1)
+    std = torch.tensor([1.0451, 1.0752, 1.0539]).view(1, 3, 1, 1)
+    image_syn = (torch.randn(n, 3, size, size, generator=g) * std + mean).to(dev)
+    text_syn = (torch.randn(n, d_txt, generator=g) * 0.5253 - 0.0094).to(dev)
+    lr = torch.tensor([0.1, 0.1], device=dev)            # syn_lr_img, syn_lr_txt (distill.py:647-648)
+    # ---- synthetic expert trajectory of THIS rank, resident in HBM: start snapshot + target
+    th0i, th0t = synthetic_expert_params(eng, seed=100 + rank, device=dev)
+    gt = torch.Generator(device=dev).manual_seed(200 + rank)
+    tgi = th0i + 1e-3 * torch.randn(th0i.shape, device=dev, generator=gt)
+    tgt = th0t + 1e-3 * torch.randn(th0t.shape, device=dev, generator=gt)
+    pg = torch.Generator().manual_seed(3)   # same permutations on every rank
+    n_img, n_txt = image_syn.numel(), text_syn.numel()
+    flat_grad = torch.zeros(n_img + n_txt + 2, device=dev)   # one fused all-reduce buffer
+    out = dict(image_syn=flat_grad[:n_img].view_as(image_syn),
+               text_syn=flat_grad[n_img:n_img + n_txt].view_as(text_syn),
+               lr=flat_grad[n_img + n_txt:], losses=torch.zeros(3 + K, device=dev))
+    mom = torch.zeros_like(flat_grad)
+    params = [(image_syn, 0, n_img, 1000.0), (text_syn, n_img, n_txt, 1000.0),
+              (lr, n_img + n_txt, 2, 1e-3)]                  # distill.py:233-241
+    P = lambda t: C.c_void_p(t.data_ptr())
+    step_no = [0]
+
+    def one_step():
+        perms = torch.stack([torch.randperm(n, generator=pg) for _ in range(K)]).to(dev)
+        eng.unrolled_match(image_syn, text_syn, lr[0:1], lr[1:2], th0i, th0t, tgi, tgt, perms=perms,
+                           out=out)
+        if world > 1:
+            dist.all_reduce(flat_grad)
+            flat_grad.div_(world)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for p, off, cnt, lrv in params:
+            _lib.check(lib.mdd_flat_sgd_momentum(P(p), P(flat_grad[off:off + cnt]), P(mom[off:off + cnt]),
+                                                 lrv * 1e-6, 0.5, 1 if step_no[0] == 0 else 0, cnt, st))
+        step_no[0] += 1
+
+    # NOTE: the SGD learning rates are scaled by 1e-6 here: with SYNTHETIC (untrained) experts the
+    # reference's lr=1000 blows the pixels up within a few steps (NaN => the reference breaks out of
+    # its loop, distill.py:599); the arithmetic per step is identical.
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    losses = out["losses"].cpu().tolist()
+
+    result = None
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * args.steps / dt
+        flops_iter = algorithmic_flops_per_iter(n, K) if variant == "nfnet_l0" else None
+        result = {
+            "metric": "distillation iters/sec (100 syn pairs, syn_steps=8)", "value": value,
+            "unit": "iters/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: Flickr30K-shaped, %d synthetic pairs, "
+                                   "syn_steps=%d, %s + text projection 768->2304, %dx%d images"
+                                   % (n, K, variant, size, size) if args.workload == "c2"
+                       else args.workload,
+                       "global_batch": n, "syn_steps": K,
+                       "parallelism": "expert-replica x%d (1 all-reduce/step)" % world},
+            "grand_loss": losses[0],
+        }
+        if flops_iter:
+            result["algorithmic_tflops_per_iter"] = flops_iter / 1e12
+            result["mfma_util_pct"] = 100.0 * flops_iter * value / world / (
+                (PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS) * 1e12)
+
+    # ---- roofline of the dominant kernel: one extra, HIP-event-instrumented iteration (rank 0)
+    if rank == 0 and not args.no_roofline:
+        lib.mdd_engine_profile(eng.h, 1)
+        one_step()
+        torch.cuda.synchronize()
+        kinds = []
+        buf = (C.c_double * 4)()
+        for k in range(4):
+            _lib.check(lib.mdd_engine_profile_read(eng.h, k, buf))
+            kinds.append(dict(kernel=KIND_NAMES[k], launches=int(buf[0]), ms=buf[1], flops=buf[2],
+                              bytes=buf[3]))
+        lib.mdd_engine_profile(eng.h, 0)
+        dom = max(kinds, key=lambda d: d["ms"])
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(dom["kernel"])
+            except Exception:
+                traffic = None
+        result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                              "frac": ach / peak, "traffic": traffic, "kernel": dom["kernel"],
+                              "avg_launch_ms": dom["ms"] / max(1, dom["launches"]),
+                              "launches_per_iter": dom["launches"],
+                              "algorithmic_gbytes_per_s": dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+                              if dom["ms"] > 0 else 0.0}
+        result["kernels"] = [dict(kernel=d["kernel"], launches=d["launches"], ms=round(d["ms"], 3),
+                                  tflops=round(d["flops"] / max(d["ms"], 1e-9) / 1e9, 2),
+                                  gbps=round(d["bytes"] / max(d["ms"], 1e-9) / 1e6, 1)) for d in kinds]
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.workload)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

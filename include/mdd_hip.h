@@ -75,8 +75,13 @@ int mdd_engine_find_buffer(const mdd_engine* e, const char* name, int slot, int6
 /* ---- image encoder passes (slot = inner step index whose activations are kept) */
 int mdd_img_forward(mdd_engine* e, int slot, const float* theta_dev, const float* image_syn_dev,
                     const int64_t* idx_dev, float* feat_out_dev, void* stream);
+/* gtheta = J_theta^T feat_bar.  If dimage_accum_dev != NULL also
+ * dimage_accum[idx] += coef*mul * J_image^T feat_bar.  stash != 0 keeps the backward signals of
+ * this slot for the tangent pass (the inner-gradient call); stash == 0 leaves them untouched (a
+ * second backward through the same forward, as the outer backward of distill.py:606 performs). */
 int mdd_img_backward(mdd_engine* e, int slot, const float* theta_dev, const float* feat_bar_dev,
-                     float* gtheta_out_dev, void* stream);
+                     float* gtheta_out_dev, float* dimage_accum_dev, const int64_t* idx_dev,
+                     const float* coef_dev, float mul, int stash, void* stream);
 int mdd_img_tangent_forward(mdd_engine* e, int slot, const float* theta_dev,
                             const float* theta_dot_dev, float* feat_dot_out_dev, void* stream);
 /* dimage_accum[idx] += coef*mul * d/d(image) ; coef_dev may be NULL (=1) */
@@ -91,7 +96,8 @@ int mdd_txt_forward(mdd_engine* e, int slot, const float* theta_dev, const float
                     const int64_t* idx_dev, const float* drop_mask_dev, float* feat_out_dev,
                     void* stream);
 int mdd_txt_backward(mdd_engine* e, int slot, const float* theta_dev, const float* feat_bar_dev,
-                     float* gtheta_out_dev, void* stream);
+                     float* gtheta_out_dev, float* dtext_accum_dev, const int64_t* idx_dev,
+                     const float* coef_dev, float mul, int stash, void* stream);
 int mdd_txt_tangent_forward(mdd_engine* e, int slot, const float* theta_dev,
                             const float* theta_dot_dev, float* feat_dot_out_dev, void* stream);
 int mdd_txt_tangent_backward(mdd_engine* e, int slot, const float* theta_dev,
@@ -138,6 +144,12 @@ typedef struct mdd_iter_args {
   float* losses;             /* out [3 + syn_steps]: grand, img, txt, contrastive per step     */
 } mdd_iter_args;
 int mdd_unrolled_match(mdd_engine* e, const mdd_iter_args* a, void* stream);
+
+/* ---- per-kernel HIP-event timing of the contraction launches (bench.py roofline accounting).
+ * kind: 0 = conv_gemm 128x32 tile, 1 = conv_gemm 256x64, 2 = conv_gemm 128x128, 3 = conv_wgrad.
+ * out4 = {launches, total milliseconds, algorithmic FLOPs, algorithmic bytes} since enable. */
+int mdd_engine_profile(mdd_engine* e, int enable);
+int mdd_engine_profile_read(mdd_engine* e, int kind, double* out4);
 
 /* ---- single-op entry points (parity tests; NHWC activations, dtype = MDD_DTYPE_*) */
 int mdd_op_conv2d(int dtype, int transposed, int nimg, int hin, int win, int cin, int cout, int k,

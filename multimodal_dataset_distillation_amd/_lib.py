@@ -45,11 +45,11 @@ SIGNATURES = {
     "mdd_engine_find_buffer": (_I, [_P, C.c_char_p, _I, C.POINTER(_L), C.POINTER(_L),
                                     C.POINTER(_I)]),
     "mdd_img_forward": (_I, [_P, _I, _P, _P, _P, _P, _P]),
-    "mdd_img_backward": (_I, [_P, _I, _P, _P, _P, _P]),
+    "mdd_img_backward": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
     "mdd_img_tangent_forward": (_I, [_P, _I, _P, _P, _P, _P]),
     "mdd_img_tangent_backward": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P]),
     "mdd_txt_forward": (_I, [_P, _I, _P, _P, _P, _P, _P, _P]),
-    "mdd_txt_backward": (_I, [_P, _I, _P, _P, _P, _P]),
+    "mdd_txt_backward": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
     "mdd_txt_tangent_forward": (_I, [_P, _I, _P, _P, _P, _P]),
     "mdd_txt_tangent_backward": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P]),
     "mdd_contrastive": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P]),
@@ -57,6 +57,8 @@ SIGNATURES = {
     "mdd_flat_axpy": (_I, [_P, _P, _P, _P, _F, _L, _P]),
     "mdd_flat_sqdist": (_I, [_P, _P, _P, _L, _P]),
     "mdd_flat_sgd_momentum": (_I, [_P, _P, _P, _F, _F, _I, _L, _P]),
+    "mdd_engine_profile": (_I, [_P, _I]),
+    "mdd_engine_profile_read": (_I, [_P, _I, C.POINTER(C.c_double)]),
     "mdd_unrolled_match": (_I, [_P, C.POINTER(MddIterArgs), _P]),
     "mdd_op_conv2d": (_I, [_I] * 11 + [_P, _P, _P, _P, _P]),
     "mdd_op_conv2d_wgrad": (_I, [_I] * 10 + [_P, _P, _P, _P, _P]),

@@ -113,17 +113,19 @@ struct mdd_engine {
                           const int64_t* idx, float* feat_out, hipStream_t st) = 0;
   virtual int img_backward(bool T, int slot, const float* th, const float* th_t, const float* ybar,
                            const float* ybar_t, float* gout, float* dimage, const int64_t* idx,
-                           const float* coef, float mul, bool repack, hipStream_t st) = 0;
+                           const float* coef, float mul, bool repack, bool stash, hipStream_t st) = 0;
   virtual int txt_forward(bool T, int slot, const float* th, const float* th_t, const float* text,
                           const int64_t* idx, const float* mask, float* feat_out,
                           hipStream_t st) = 0;
   virtual int txt_backward(bool T, int slot, const float* th, const float* th_t, const float* ybar,
                            const float* ybar_t, float* gout, float* dtext, const int64_t* idx,
-                           const float* coef, float mul, hipStream_t st) = 0;
+                           const float* coef, float mul, bool stash, hipStream_t st) = 0;
   virtual int contrastive(bool T, const float* x, const float* y, const float* x_t,
                           const float* y_t, const float* scale_dev, float scale_const, float* loss,
                           float* xbar, float* ybar, float* sbar, hipStream_t st) = 0;
   virtual int unrolled_match(const mdd_iter_args* a, hipStream_t st) = 0;
+  virtual void profile_enable(bool on) = 0;
+  virtual int profile_read(int kind, double* out4) = 0;
   std::vector<ParamInfo> pimg, ptxt;
   int64_t P_img = 0, P_txt = 0;
   int feat = 0;
@@ -297,7 +299,7 @@ struct Eng : mdd_engine {
     int nb = (int)blks.size();
     auto nm = [&](const std::string& n) { return n; };
     int64_t n = N;
-    plan(&s.X0, n * S * S * 8, "X0", slot);
+    plan(&s.X0, n * S * S * 8, "IN", slot);
     for (int i = 0; i < 3; ++i) {
       const ConvL& L = convs[stem[i]];
       int64_t e = n * L.hout * L.hout * L.cout;
@@ -306,7 +308,7 @@ struct Eng : mdd_engine {
       plan(&s.AsB[i], e, ("stem.AB" + std::to_string(i)).c_str(), slot);
       plan(&s.CsB[i], e, ("stem.CB" + std::to_string(i)).c_str(), slot);
     }
-    plan(&s.X0B, n * S * S * 8, "X0B", slot);
+    plan(&s.X0B, n * S * S * 8, "INB", slot);
     s.X.resize(nb + 1); s.A.resize(nb + 1); s.XB.resize(nb + 1); s.blk.resize(nb);
     for (int b = 0; b <= nb; ++b) {
       int64_t e = n * xh[b] * xh[b] * xc[b];
@@ -414,6 +416,56 @@ struct Eng : mdd_engine {
     g.transposed = 1; return g;
   }
 
+  // ---- optional HIP-event timing of every contraction launch (bench.py roofline accounting)
+  struct Prof { int kind; double flops, bytes; hipEvent_t a, b; };
+  bool prof_on = false;
+  std::vector<Prof> prof;
+  void profile_enable(bool on) override {
+    for (auto& p : prof) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    prof.clear(); prof_on = on;
+  }
+  int profile_read(int kind, double* out) override {  // {launches, total ms, flops, bytes}
+    out[0] = out[1] = out[2] = out[3] = 0;
+    for (auto& p : prof) if (p.kind == kind) {
+      float ms = 0; HIP_CHECK_RET(hipEventSynchronize(p.b)); HIP_CHECK_RET(hipEventElapsedTime(&ms, p.a, p.b));
+      out[0] += 1; out[1] += ms; out[2] += p.flops; out[3] += p.bytes;
+    }
+    return 0;
+  }
+  double conv_macs(const ConvL& L) const {
+    return (double)N * L.hout * L.hout * L.cout * (L.cin / L.groups) * L.k * L.k;
+  }
+  void gemm(const ConvL& L, const ConvGeom& g, const AT* A1, const AT* B1, const AT* A2, const AT* B2,
+            const ConvEpi& e, hipStream_t st) {
+    if (!prof_on) { launch_conv_gemm<AT>(g, A1, B1, A2, B2, e, st); return; }
+    Prof p; int ns = A2 ? 2 : 1;
+    p.kind = g.nc <= 32 ? 0 : (g.nc <= 64 ? 1 : 2);
+    p.flops = 2.0 * conv_macs(L) * ns;
+    double ain = (double)g.nimg * g.ha * g.wa * g.ca_tot, aout = (double)g.nimg * g.ho * g.wo * g.co_tot;
+    int nio = (e.out_raw ? 1 : 0) + (e.out_act ? 1 : 0) + (e.c ? 1 : 0) + (e.c_t ? 1 : 0) +
+              (e.abar ? 1 : 0) + (e.add1 ? 1 : 0) + (e.add2 ? 1 : 0);
+    p.bytes = (ain * ns + (double)L.packed() * ns + aout * nio) * sizeof(AT);
+    hipEventCreate(&p.a); hipEventCreate(&p.b);
+    hipEventRecord(p.a, st);
+    launch_conv_gemm<AT>(g, A1, B1, A2, B2, e, st);
+    hipEventRecord(p.b, st);
+    prof.push_back(p);
+  }
+  void wgrad(const ConvL& L, const ConvGeom& g, const AT* dy1, const AT* x1, const AT* dy2, const AT* x2,
+             float* dW, float* db, hipStream_t st) {
+    if (!prof_on) { launch_conv_wgrad<AT>(g, dy1, x1, dy2, x2, dW, db, st); return; }
+    Prof p; int ns = dy2 ? 2 : 1;
+    p.kind = 3;
+    p.flops = 2.0 * conv_macs(L) * ns;
+    double ain = (double)g.nimg * g.ha * g.wa * g.ca_tot, aout = (double)g.nimg * g.ho * g.wo * g.co_tot;
+    p.bytes = (ain + aout) * ns * sizeof(AT) + (double)L.packed() * 4;
+    hipEventCreate(&p.a); hipEventCreate(&p.b);
+    hipEventRecord(p.a, st);
+    launch_conv_wgrad<AT>(g, dy1, x1, dy2, x2, dW, db, st);
+    hipEventRecord(p.b, st);
+    prof.push_back(p);
+  }
+
   // c = conv(in) + bias ; C <- c ; A <- beta*silu(c).   T: tangent of the same (primal from stash)
   void conv_fwd(bool T, const ConvL& L, const AT* in, const AT* in_t, AT* C, AT* C_t, AT* A,
                 AT* A_t, float beta, const float* th, const float* th_t, hipStream_t st) {
@@ -422,25 +474,25 @@ struct Eng : mdd_engine {
     e.beta = beta;
     if (!T) {
       e.mode = EPI_FWD; e.bias = th + L.off_b; e.out_raw = C; e.out_act = A;
-      launch_conv_gemm<AT>(g, in, wf + L.off_p, nullptr, nullptr, e, st);
+      gemm(L, g, in, wf + L.off_p, nullptr, nullptr, e, st);
     } else {
       e.mode = EPI_FWD_T; e.bias_t = th_t + L.off_b; e.out_raw = C_t; e.out_act = A_t; e.c = C;
-      if (in_t) launch_conv_gemm<AT>(g, in_t, wf + L.off_p, in, wf_t + L.off_p, e, st);
-      else launch_conv_gemm<AT>(g, in, wf_t + L.off_p, nullptr, nullptr, e, st);
+      if (in_t) gemm(L, g, in_t, wf + L.off_p, in, wf_t + L.off_p, e, st);
+      else gemm(L, g, in, wf_t + L.off_p, nullptr, nullptr, e, st);
     }
   }
   // weight + bias gradient of conv L (dy = grad wrt its raw output, x = its input)
   void conv_bwd_w(bool T, const ConvL& L, const AT* dy, const AT* dy_t, const AT* x, const AT* x_t,
                   float* dwf_, float* dwf_t_, float* gout, hipStream_t st) {
     ConvGeom g = gfwd(L);
-    if (!T) launch_conv_wgrad<AT>(g, dy, x, nullptr, nullptr, dwf_ + L.off_p, gout + L.off_b, st);
-    else launch_conv_wgrad<AT>(g, dy_t, x, x_t ? dy : nullptr, x_t, dwf_t_ + L.off_p, gout + L.off_b, st);
+    if (!T) wgrad(L, g, dy, x, nullptr, nullptr, dwf_ + L.off_p, gout + L.off_b, st);
+    else wgrad(L, g, dy_t, x, x_t ? dy : nullptr, x_t, dwf_t_ + L.off_p, gout + L.off_b, st);
   }
   // data gradient of conv L with fused epilogue
   void conv_bwd_d(bool T, const ConvL& L, const AT* dy, const AT* dy_t, ConvEpi e, hipStream_t st) {
     ConvGeom g = gdgrad(L);
-    if (!T) launch_conv_gemm<AT>(g, dy, wt + L.off_p, nullptr, nullptr, e, st);
-    else launch_conv_gemm<AT>(g, dy_t, wt + L.off_p, dy, wt_t + L.off_p, e, st);
+    if (!T) gemm(L, g, dy, wt + L.off_p, nullptr, nullptr, e, st);
+    else gemm(L, g, dy_t, wt + L.off_p, dy, wt_t + L.off_p, e, st);
   }
   ConvEpi epi_act(bool T, AT* raw, AT* act, AT* act_t, const AT* c, const AT* c_t, float beta,
                   const AT* add1, const AT* add2) {
@@ -517,57 +569,59 @@ struct Eng : mdd_engine {
   // ------------------------------------------------------------------ image encoder: B / T-bwd
   int img_backward(bool T, int slot, const float* th, const float* th_t, const float* ybar_in,
                    const float* ybar_t_in, float* gout, float* dimage, const int64_t* idx,
-                   const float* coef, float mul, bool repack, hipStream_t st) override {
+                   const float* coef, float mul, bool repack, bool stash, hipStream_t st) override {
     CHECK_ARG(base, "workspace not bound");
     CHECK_ARG(slot >= 0 && slot < K, "slot out of range");
     ActSet& P = sets[slot]; ActSet& Q = tn;
+    ActSet& O = (!T && !stash) ? tn : P;  // where primal backward signals are written
     int nb = (int)blks.size();
     if (repack)
       launch_ws_forward<AT>(d_descs, (int)descs.size(), total_rows, th, T ? th_t : nullptr, wf, wt,
                             wf_t, wt_t, st);
-    float* dw = P.dwf; float* dw_t = Q.dwf;
+    float* dw = O.dwf; float* dw_t = Q.dwf;
     HIP_CHECK_RET(hipMemsetAsync(T ? dw_t : dw, 0, packed_total * 4, st));
     HIP_CHECK_RET(hipMemsetAsync(gout, 0, P_img * 4, st));
-    if (!T && ybar_in != P.yB)
-      HIP_CHECK_RET(hipMemcpyAsync(P.yB, ybar_in, (size_t)N * feat * 4, hipMemcpyDeviceToDevice, st));
+    if (!T && ybar_in != O.yB)
+      HIP_CHECK_RET(hipMemcpyAsync(O.yB, ybar_in, (size_t)N * feat * 4, hipMemcpyDeviceToDevice, st));
     const float ga = nf.attn_gain * nf.alpha;
     int hwf = xh[nb] * xh[nb];
-    launch_final_pool_bwd<AT>(P.CFB, T ? Q.CFB : nullptr, P.yB, T ? ybar_t_in : nullptr, P.CF,
+    launch_final_pool_bwd<AT>(O.CFB, T ? Q.CFB : nullptr, O.yB, T ? ybar_t_in : nullptr, P.CF,
                               T ? Q.CF : nullptr, N, hwf, feat, st);
-    conv_bwd_w(T, convs[fin], P.CFB, Q.CFB, P.X[nb], Q.X[nb], dw, dw_t, gout, st);
-    conv_bwd_d(T, convs[fin], P.CFB, Q.CFB, epi_lin(T ? Q.XB[nb] : P.XB[nb], nullptr), st);
+    conv_bwd_w(T, convs[fin], O.CFB, Q.CFB, P.X[nb], Q.X[nb], dw, dw_t, gout, st);
+    conv_bwd_d(T, convs[fin], O.CFB, Q.CFB, epi_lin(T ? Q.XB[nb] : O.XB[nb], nullptr), st);
     for (int b = nb - 1; b >= 0; --b) {
       const Blk& B = blks[b]; BlockActs& pa = P.blk[b]; BlockActs& qa = Q.blk[b];
-      const AT *xb = P.XB[b + 1], *xb_t = Q.XB[b + 1];
+      BlockActs& oa = O.blk[b];
+      const AT *xb = O.XB[b + 1], *xb_t = Q.XB[b + 1];
       int hw = B.hout * B.hout, c = B.se.c, rd = B.se.rd;
       // squeeze-excite backward
-      launch_se_gate_grad<AT>(pa.gateB, T ? qa.gateB : nullptr, xb, T ? xb_t : nullptr, pa.C3,
+      launch_se_gate_grad<AT>(oa.gateB, T ? qa.gateB : nullptr, xb, T ? xb_t : nullptr, pa.C3,
                               T ? qa.C3 : nullptr, ga, N, hw, c, st);
-      launch_small_pointwise(0, pa.zB, T ? qa.zB : nullptr, pa.gateB, T ? qa.gateB : nullptr,
+      launch_small_pointwise(0, oa.zB, T ? qa.zB : nullptr, oa.gateB, T ? qa.gateB : nullptr,
                              pa.gate, T ? qa.gate : nullptr, N * c, st);
-      launch_linear_wgrad(gout + B.se.off_w2, gout + B.se.off_b2, pa.zB, T ? qa.zB : nullptr, pa.h,
+      launch_linear_wgrad(gout + B.se.off_w2, gout + B.se.off_b2, oa.zB, T ? qa.zB : nullptr, pa.h,
                           T ? qa.h : nullptr, N, rd, c, st);
-      launch_linear_dgrad(se_tmp, T ? se_tmp_t : nullptr, pa.zB, T ? qa.zB : nullptr,
+      launch_linear_dgrad(se_tmp, T ? se_tmp_t : nullptr, oa.zB, T ? qa.zB : nullptr,
                           th + B.se.off_w2, T ? th_t + B.se.off_w2 : nullptr, N, rd, c, st);
-      launch_small_pointwise(1, pa.hB, T ? qa.hB : nullptr, se_tmp, T ? se_tmp_t : nullptr, pa.h,
+      launch_small_pointwise(1, oa.hB, T ? qa.hB : nullptr, se_tmp, T ? se_tmp_t : nullptr, pa.h,
                              T ? qa.h : nullptr, N * rd, st);
-      launch_linear_wgrad(gout + B.se.off_w1, gout + B.se.off_b1, pa.hB, T ? qa.hB : nullptr, pa.p,
+      launch_linear_wgrad(gout + B.se.off_w1, gout + B.se.off_b1, oa.hB, T ? qa.hB : nullptr, pa.p,
                           T ? qa.p : nullptr, N, c, rd, st);
-      launch_linear_dgrad(pa.pB, T ? qa.pB : nullptr, pa.hB, T ? qa.hB : nullptr, th + B.se.off_w1,
+      launch_linear_dgrad(oa.pB, T ? qa.pB : nullptr, oa.hB, T ? qa.hB : nullptr, th + B.se.off_w1,
                           T ? th_t + B.se.off_w1 : nullptr, N, c, rd, st);
-      launch_se_apply_bwd<AT>(pa.C3B, T ? qa.C3B : nullptr, xb, T ? xb_t : nullptr, pa.gate,
-                              T ? qa.gate : nullptr, pa.pB, T ? qa.pB : nullptr, ga, N, hw, c, st);
+      launch_se_apply_bwd<AT>(oa.C3B, T ? qa.C3B : nullptr, xb, T ? xb_t : nullptr, pa.gate,
+                              T ? qa.gate : nullptr, oa.pB, T ? qa.pB : nullptr, ga, N, hw, c, st);
       // residual branch
-      conv_bwd_w(T, convs[B.c3], pa.C3B, qa.C3B, pa.A2b, qa.A2b, dw, dw_t, gout, st);
-      conv_bwd_d(T, convs[B.c3], pa.C3B, qa.C3B,
-                 epi_act(T, pa.A2bB, pa.C2bB, qa.C2bB, pa.C2b, qa.C2b, 1.f, nullptr, nullptr), st);
-      conv_bwd_w(T, convs[B.c2b], pa.C2bB, qa.C2bB, pa.A2, qa.A2, dw, dw_t, gout, st);
-      conv_bwd_d(T, convs[B.c2b], pa.C2bB, qa.C2bB,
-                 epi_act(T, pa.A2B, pa.C2B, qa.C2B, pa.C2, qa.C2, 1.f, nullptr, nullptr), st);
-      conv_bwd_w(T, convs[B.c2], pa.C2B, qa.C2B, pa.A1, qa.A1, dw, dw_t, gout, st);
-      conv_bwd_d(T, convs[B.c2], pa.C2B, qa.C2B,
-                 epi_act(T, pa.A1B, pa.C1B, qa.C1B, pa.C1, qa.C1, 1.f, nullptr, nullptr), st);
-      conv_bwd_w(T, convs[B.c1], pa.C1B, qa.C1B, P.A[b], Q.A[b], dw, dw_t, gout, st);
+      conv_bwd_w(T, convs[B.c3], oa.C3B, qa.C3B, pa.A2b, qa.A2b, dw, dw_t, gout, st);
+      conv_bwd_d(T, convs[B.c3], oa.C3B, qa.C3B,
+                 epi_act(T, oa.A2bB, oa.C2bB, qa.C2bB, pa.C2b, qa.C2b, 1.f, nullptr, nullptr), st);
+      conv_bwd_w(T, convs[B.c2b], oa.C2bB, qa.C2bB, pa.A2, qa.A2, dw, dw_t, gout, st);
+      conv_bwd_d(T, convs[B.c2b], oa.C2bB, qa.C2bB,
+                 epi_act(T, oa.A2B, oa.C2B, qa.C2B, pa.C2, qa.C2, 1.f, nullptr, nullptr), st);
+      conv_bwd_w(T, convs[B.c2], oa.C2B, qa.C2B, pa.A1, qa.A1, dw, dw_t, gout, st);
+      conv_bwd_d(T, convs[B.c2], oa.C2B, qa.C2B,
+                 epi_act(T, oa.A1B, oa.C1B, qa.C1B, pa.C1, qa.C1, 1.f, nullptr, nullptr), st);
+      conv_bwd_w(T, convs[B.c1], oa.C1B, qa.C1B, P.A[b], Q.A[b], dw, dw_t, gout, st);
       // shortcut branch
       const AT* add1 = nullptr;
       if (B.ds >= 0) {
@@ -583,24 +637,24 @@ struct Eng : mdd_engine {
         }
       }
       // conv1 dgrad + pre-activation chain rule + identity shortcut:  XB[b] = beta*silu'(X[b])*Abar (+ XB[b+1])
-      conv_bwd_d(T, convs[B.c1], pa.C1B, qa.C1B,
-                 epi_act(T, pa.AinB, P.XB[b], Q.XB[b], P.X[b], Q.X[b], B.beta, add1,
+      conv_bwd_d(T, convs[B.c1], oa.C1B, qa.C1B,
+                 epi_act(T, oa.AinB, O.XB[b], Q.XB[b], P.X[b], Q.X[b], B.beta, add1,
                          B.ds >= 0 ? nullptr : (T ? xb_t : xb)), st);
     }
     // stem (conv4 output is the raw stream X[0]; its grad is XB[0])
-    conv_bwd_w(T, convs[stem[3]], P.XB[0], Q.XB[0], P.As[2], Q.As[2], dw, dw_t, gout, st);
-    conv_bwd_d(T, convs[stem[3]], P.XB[0], Q.XB[0],
-               epi_act(T, P.AsB[2], P.CsB[2], Q.CsB[2], P.Cs[2], Q.Cs[2], 1.f, nullptr, nullptr), st);
-    conv_bwd_w(T, convs[stem[2]], P.CsB[2], Q.CsB[2], P.As[1], Q.As[1], dw, dw_t, gout, st);
-    conv_bwd_d(T, convs[stem[2]], P.CsB[2], Q.CsB[2],
-               epi_act(T, P.AsB[1], P.CsB[1], Q.CsB[1], P.Cs[1], Q.Cs[1], 1.f, nullptr, nullptr), st);
-    conv_bwd_w(T, convs[stem[1]], P.CsB[1], Q.CsB[1], P.As[0], Q.As[0], dw, dw_t, gout, st);
-    conv_bwd_d(T, convs[stem[1]], P.CsB[1], Q.CsB[1],
-               epi_act(T, P.AsB[0], P.CsB[0], Q.CsB[0], P.Cs[0], Q.Cs[0], 1.f, nullptr, nullptr), st);
-    conv_bwd_w(T, convs[stem[0]], P.CsB[0], Q.CsB[0], P.X0, nullptr, dw, dw_t, gout, st);
+    conv_bwd_w(T, convs[stem[3]], O.XB[0], Q.XB[0], P.As[2], Q.As[2], dw, dw_t, gout, st);
+    conv_bwd_d(T, convs[stem[3]], O.XB[0], Q.XB[0],
+               epi_act(T, O.AsB[2], O.CsB[2], Q.CsB[2], P.Cs[2], Q.Cs[2], 1.f, nullptr, nullptr), st);
+    conv_bwd_w(T, convs[stem[2]], O.CsB[2], Q.CsB[2], P.As[1], Q.As[1], dw, dw_t, gout, st);
+    conv_bwd_d(T, convs[stem[2]], O.CsB[2], Q.CsB[2],
+               epi_act(T, O.AsB[1], O.CsB[1], Q.CsB[1], P.Cs[1], Q.Cs[1], 1.f, nullptr, nullptr), st);
+    conv_bwd_w(T, convs[stem[1]], O.CsB[1], Q.CsB[1], P.As[0], Q.As[0], dw, dw_t, gout, st);
+    conv_bwd_d(T, convs[stem[1]], O.CsB[1], Q.CsB[1],
+               epi_act(T, O.AsB[0], O.CsB[0], Q.CsB[0], P.Cs[0], Q.Cs[0], 1.f, nullptr, nullptr), st);
+    conv_bwd_w(T, convs[stem[0]], O.CsB[0], Q.CsB[0], P.X0, nullptr, dw, dw_t, gout, st);
     if (dimage) {
-      AT* x0b = T ? Q.X0B : P.X0B;
-      conv_bwd_d(T, convs[stem[0]], P.CsB[0], Q.CsB[0], epi_lin(x0b, nullptr), st);
+      AT* x0b = T ? Q.X0B : O.X0B;
+      conv_bwd_d(T, convs[stem[0]], O.CsB[0], Q.CsB[0], epi_lin(x0b, nullptr), st);
       launch_img_scatter_grad<AT>(dimage, x0b, idx, coef, mul, N, 3, S, S, 8, st);
     }
     launch_ws_backward(d_descs, (int)descs.size(), total_rows, th, T ? th_t : nullptr, dw,
@@ -636,27 +690,28 @@ struct Eng : mdd_engine {
 
   int txt_backward(bool T, int slot, const float* th, const float* th_t, const float* ybar_in,
                    const float* ybar_t_in, float* gout, float* dtext, const int64_t* idx,
-                   const float* coef, float mul, hipStream_t st) override {
+                   const float* coef, float mul, bool stash, hipStream_t st) override {
     CHECK_ARG(base, "workspace not bound");
     CHECK_ARG(slot >= 0 && slot < K, "slot out of range");
     ActSet& P = sets[slot]; ActSet& Q = tn;
+    ActSet& O = (!T && !stash) ? tn : P;
     auto tt = [&](int64_t o) { return T ? th_t + o : nullptr; };
-    if (!T && ybar_in != P.tyB)
-      HIP_CHECK_RET(hipMemcpyAsync(P.tyB, ybar_in, (size_t)N * feat * 4, hipMemcpyDeviceToDevice, st));
-    launch_ln_bwd(P.trB, T ? Q.trB : nullptr, P.tfB, T ? Q.tfB : nullptr, gout + t_lw, gout + t_lb,
-                  ln_stats, P.tyB, T ? ybar_t_in : nullptr, P.tr, T ? Q.tr : nullptr,
+    if (!T && ybar_in != O.tyB)
+      HIP_CHECK_RET(hipMemcpyAsync(O.tyB, ybar_in, (size_t)N * feat * 4, hipMemcpyDeviceToDevice, st));
+    launch_ln_bwd(O.trB, T ? Q.trB : nullptr, O.tfB, T ? Q.tfB : nullptr, gout + t_lw, gout + t_lb,
+                  ln_stats, O.tyB, T ? ybar_t_in : nullptr, P.tr, T ? Q.tr : nullptr,
                   slot_mask_[slot], th + t_lw, tt(t_lw), N, feat, 1e-5f, st);
-    launch_linear_wgrad(gout + t_fw, gout + t_fb, P.tfB, T ? Q.tfB : nullptr, P.tg,
+    launch_linear_wgrad(gout + t_fw, gout + t_fb, O.tfB, T ? Q.tfB : nullptr, P.tg,
                         T ? Q.tg : nullptr, N, feat, feat, st);
-    launch_linear_dgrad(P.tgB, T ? Q.tgB : nullptr, P.tfB, T ? Q.tfB : nullptr, th + t_fw, tt(t_fw),
+    launch_linear_dgrad(O.tgB, T ? Q.tgB : nullptr, O.tfB, T ? Q.tfB : nullptr, th + t_fw, tt(t_fw),
                         N, feat, feat, st);
-    launch_gelu_bwd(P.tpB, T ? Q.tpB : nullptr, P.trB, T ? Q.trB : nullptr, P.tgB,
+    launch_gelu_bwd(O.tpB, T ? Q.tpB : nullptr, O.trB, T ? Q.trB : nullptr, O.tgB,
                     T ? Q.tgB : nullptr, P.tp, T ? Q.tp : nullptr, (int64_t)N * feat, st);
-    launch_linear_wgrad(gout + t_pw, gout + t_pb, P.tpB, T ? Q.tpB : nullptr, P.tx, nullptr, N, Dt,
+    launch_linear_wgrad(gout + t_pw, gout + t_pb, O.tpB, T ? Q.tpB : nullptr, P.tx, nullptr, N, Dt,
                         feat, st);
     if (dtext) {
-      float* xb = T ? Q.txB : P.txB;
-      launch_linear_dgrad(P.txB, T ? Q.txB : nullptr, P.tpB, T ? Q.tpB : nullptr, th + t_pw,
+      float* xb = T ? Q.txB : O.txB;
+      launch_linear_dgrad(O.txB, T ? Q.txB : nullptr, O.tpB, T ? Q.tpB : nullptr, th + t_pw,
                           tt(t_pw), N, Dt, feat, st);
       launch_scatter_rows_axpy(dtext, xb, idx, coef, mul, N, Dt, st);
     }
@@ -699,9 +754,9 @@ struct Eng : mdd_engine {
                             a->logit_scale_const, a->losses + 3 + k, sets[k].yB, sets[k].tyB, sbar, st)))
         return rc;
       if ((rc = img_backward(false, k, tI[k], nullptr, sets[k].yB, nullptr, gI[k], nullptr, nullptr,
-                             nullptr, 0.f, false, st))) return rc;
+                             nullptr, 0.f, false, true, st))) return rc;
       if ((rc = txt_backward(false, k, tT[k], nullptr, sets[k].tyB, nullptr, gT[k], nullptr, nullptr,
-                             nullptr, 0.f, st))) return rc;
+                             nullptr, 0.f, true, st))) return rc;
       launch_axpy_out(thI[k + 1], tI[k], gI[k], a->lr_img, -1.f, P_img, st);
       launch_axpy_out(thT[k + 1], tT[k], gT[k], a->lr_txt, -1.f, P_txt, st);
     }
@@ -727,9 +782,9 @@ struct Eng : mdd_engine {
       if ((rc = contrastive(true, sets[k].y, sets[k].ty, fx_t, fy_t, scale_dev, a->logit_scale_const,
                             nullptr, xbar_t, ybar_t, sbar_t, st))) return rc;
       if ((rc = img_backward(true, k, tI[k], nuI, nullptr, xbar_t, hI, a->grad_image_syn, idx, nullptr,
-                             -1.f, false, st))) return rc;
+                             -1.f, false, true, st))) return rc;
       if ((rc = txt_backward(true, k, tT[k], nuT, nullptr, ybar_t, hT, a->grad_text_syn, idx, nullptr,
-                             -1.f, st))) return rc;
+                             -1.f, true, st))) return rc;
       if (a->use_lr_as_scale) launch_accum_f2d(dsc + 4, sbar_t, -1.0, st);
       launch_sub_inplace(lamI, hI, P_img, st);
       launch_sub_inplace(lamT, hT, P_txt, st);
@@ -810,10 +865,11 @@ int mdd_img_forward(mdd_engine* e, int slot, const float* th, const float* image
   return e->img_forward(false, slot, th, nullptr, image, idx, feat_out, (hipStream_t)stream);
 }
 int mdd_img_backward(mdd_engine* e, int slot, const float* th, const float* fb, float* gout,
+                     float* dimage, const int64_t* idx, const float* coef, float mul, int stash,
                      void* stream) {
   CHECK_ARG(e && th && fb && gout, "null pointer");
-  return e->img_backward(false, slot, th, nullptr, fb, nullptr, gout, nullptr, nullptr, nullptr, 0.f,
-                         true, (hipStream_t)stream);
+  return e->img_backward(false, slot, th, nullptr, fb, nullptr, gout, dimage, idx, coef, mul, true,
+                         stash != 0, (hipStream_t)stream);
 }
 int mdd_img_tangent_forward(mdd_engine* e, int slot, const float* th, const float* thd,
                             float* fdot, void* stream) {
@@ -825,7 +881,7 @@ int mdd_img_tangent_backward(mdd_engine* e, int slot, const float* th, const flo
                              const float* coef, float mul, void* stream) {
   CHECK_ARG(e && th && thd && fbd && hout, "null pointer");
   return e->img_backward(true, slot, th, thd, nullptr, fbd, hout, dimage, idx, coef, mul, true,
-                         (hipStream_t)stream);
+                         true, (hipStream_t)stream);
 }
 int mdd_txt_forward(mdd_engine* e, int slot, const float* th, const float* text,
                     const int64_t* idx, const float* mask, float* feat_out, void* stream) {
@@ -833,10 +889,11 @@ int mdd_txt_forward(mdd_engine* e, int slot, const float* th, const float* text,
   return e->txt_forward(false, slot, th, nullptr, text, idx, mask, feat_out, (hipStream_t)stream);
 }
 int mdd_txt_backward(mdd_engine* e, int slot, const float* th, const float* fb, float* gout,
+                     float* dtext, const int64_t* idx, const float* coef, float mul, int stash,
                      void* stream) {
   CHECK_ARG(e && th && fb && gout, "null pointer");
-  return e->txt_backward(false, slot, th, nullptr, fb, nullptr, gout, nullptr, nullptr, nullptr, 0.f,
-                         (hipStream_t)stream);
+  return e->txt_backward(false, slot, th, nullptr, fb, nullptr, gout, dtext, idx, coef, mul,
+                         stash != 0, (hipStream_t)stream);
 }
 int mdd_txt_tangent_forward(mdd_engine* e, int slot, const float* th, const float* thd,
                             float* fdot, void* stream) {
@@ -847,7 +904,7 @@ int mdd_txt_tangent_backward(mdd_engine* e, int slot, const float* th, const flo
                              const float* fbd, float* hout, float* dtext, const int64_t* idx,
                              const float* coef, float mul, void* stream) {
   CHECK_ARG(e && th && thd && fbd && hout, "null pointer");
-  return e->txt_backward(true, slot, th, thd, nullptr, fbd, hout, dtext, idx, coef, mul,
+  return e->txt_backward(true, slot, th, thd, nullptr, fbd, hout, dtext, idx, coef, mul, true,
                          (hipStream_t)stream);
 }
 int mdd_contrastive(mdd_engine* e, const float* x, const float* y, const float* scale_dev,
@@ -883,6 +940,15 @@ int mdd_flat_sgd_momentum(float* p, const float* g, float* buf, float lr, float 
   launch_sgd_momentum(p, g, buf, lr, mom, first, n, (hipStream_t)stream);
   POST_LAUNCH("sgd");
   return 0;
+}
+int mdd_engine_profile(mdd_engine* e, int enable) {
+  CHECK_ARG(e, "null engine");
+  e->profile_enable(enable != 0);
+  return 0;
+}
+int mdd_engine_profile_read(mdd_engine* e, int kind, double* out4) {
+  CHECK_ARG(e && out4 && kind >= 0 && kind < 4, "profile_read");
+  return e->profile_read(kind, out4);
 }
 int mdd_unrolled_match(mdd_engine* e, const mdd_iter_args* a, void* stream) {
   CHECK_ARG(e && a, "null pointer");

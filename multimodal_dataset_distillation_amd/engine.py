@@ -118,10 +118,12 @@ class UnrollEngine:
                                        _ptr(idx), _ptr(out), _stream()))
         return out
 
-    def img_backward(self, slot, theta, feat_bar):
+    def img_backward(self, slot, theta, feat_bar, dimage=None, idx=None, coef=None, mul=1.0,
+                     stash=True):
         g = self._new(self.P_img)
         check(self.lib.mdd_img_backward(self.h, slot, _ptr(theta), _ptr(_f32(feat_bar)), _ptr(g),
-                                        _stream()))
+                                        _ptr(dimage), _ptr(idx), _ptr(coef), float(mul),
+                                        1 if stash else 0, _stream()))
         return g
 
     def img_tangent_forward(self, slot, theta, theta_dot):
@@ -146,10 +148,12 @@ class UnrollEngine:
                                        _ptr(idx), _ptr(drop_mask), _ptr(out), _stream()))
         return out
 
-    def txt_backward(self, slot, theta, feat_bar):
+    def txt_backward(self, slot, theta, feat_bar, dtext=None, idx=None, coef=None, mul=1.0,
+                     stash=True):
         g = self._new(self.P_txt)
         check(self.lib.mdd_txt_backward(self.h, slot, _ptr(theta), _ptr(_f32(feat_bar)), _ptr(g),
-                                        _stream()))
+                                        _ptr(dtext), _ptr(idx), _ptr(coef), float(mul),
+                                        1 if stash else 0, _stream()))
         return g
 
     def txt_tangent_forward(self, slot, theta, theta_dot):

@@ -107,15 +107,16 @@ def test_flat_ops(report):
         x, g = torch.randn(n), torch.randn(n)
         lr = torch.tensor([0.37])
         out = torch.empty(n, device=dev)
-        _lib.check(lib.mdd_flat_axpy(P(out), P(x.to(dev)), P(g.to(dev)), P(lr.to(dev)), -1.0, n, st))
-        assert torch.equal(out.cpu(), x + (-1.0 * 0.37) * g) or rel_err(out, x - 0.37 * g) < 1e-7
+        xd, gd, lrd = x.to(dev), g.to(dev), lr.to(dev)   # keep alive: the ABI takes raw pointers
+        _lib.check(lib.mdd_flat_axpy(P(out), P(xd), P(gd), P(lrd), -1.0, n, st))
+        assert rel_err(out, x - 0.37 * g) < 1e-6
         acc = torch.zeros(1, dtype=torch.float64, device=dev)
-        _lib.check(lib.mdd_flat_sqdist(P(x.to(dev)), P(g.to(dev)), P(acc), n, st))
+        _lib.check(lib.mdd_flat_sqdist(P(xd), P(gd), P(acc), n, st))
         ref = ((x.double() - g.double()) ** 2).sum()
         assert abs(acc.item() - ref.item()) <= 1e-6 * ref.item() + 1e-12
         p, buf = x.clone().to(dev), torch.zeros(n, device=dev)
-        _lib.check(lib.mdd_flat_sgd_momentum(P(p), P(g.to(dev)), P(buf), 1000.0, 0.5, 1, n, st))
-        _lib.check(lib.mdd_flat_sgd_momentum(P(p), P(g.to(dev)), P(buf), 1000.0, 0.5, 0, n, st))
+        _lib.check(lib.mdd_flat_sgd_momentum(P(p), P(gd), P(buf), 1000.0, 0.5, 1, n, st))
+        _lib.check(lib.mdd_flat_sgd_momentum(P(p), P(gd), P(buf), 1000.0, 0.5, 0, n, st))
         ref_p = x - 1000.0 * g - 1000.0 * (0.5 * g + g)
         assert rel_err(p, ref_p) < 1e-6
     report("flat_ops ok")
