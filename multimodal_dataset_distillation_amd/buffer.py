@@ -1,0 +1,123 @@
+"""Stage-1 driver surface: expert trajectories for the distillation hot path (reference buffer.py).
+
+Accepts the reference's command line (buffer.py:118-161).  What it produces is the hot path's
+on-disk INPUT format, unchanged: `{buffer_path}/{dataset}/{image_encoder}/{text_encoder}/
+img_replay_buffer_{n}.pt` / `txt_replay_buffer_{n}.pt` = torch.save(list[expert] of
+list[epoch] of list[Tensor]) (buffer.py:67-68, 94-95, 104-112).
+
+Expert training itself is first-order only and is NOT the hot path.  It reuses
+the hot path's kernels: one training step = engine forward (F) + inner gradient (B) + flat SGD axpy,
+with the reference's fixed logit scale 1/0.07 (networks.py:878).  Real Flickr30K/COCO batches need
+the dataset + frozen BERT embeddings, which do not exist offline, so the only data source wired up is
+`--synthetic_data` (random image / text-embedding pairs): good for exercising the pipeline and for
+producing buffers in the reference format on an MI355X, not for training useful experts.
+"""
+import argparse
+import datetime
+import os
+
+import torch
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="Parameter Processing")
+    p.add_argument("--dataset", type=str, default="flickr", choices=["flickr", "coco", "roco"])
+    p.add_argument("--num_experts", type=int, default=100)
+    p.add_argument("--lr_teacher_img", type=float, default=0.1)
+    p.add_argument("--lr_teacher_txt", type=float, default=0.1)
+    p.add_argument("--batch_train", type=int, default=128)
+    p.add_argument("--dsa", type=str, default="True", choices=["True", "False"])
+    p.add_argument("--dsa_strategy", type=str, default="color_crop_cutout_flip_scale_rotate")
+    p.add_argument("--data_path", type=str, default="./data/Flickr30k/")
+    p.add_argument("--buffer_path", type=str, default="./buffers")
+    p.add_argument("--train_epochs", type=int, default=50)
+    p.add_argument("--zca", action="store_true")
+    p.add_argument("--decay", action="store_true")
+    p.add_argument("--mom", type=float, default=0)
+    p.add_argument("--l2", type=float, default=0)
+    p.add_argument("--save_interval", type=int, default=10)
+    p.add_argument("--name", type=str, default=datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S"))
+    p.add_argument("--text_pretrained", type=bool, default=True)
+    p.add_argument("--image_pretrained", type=bool, default=True)
+    p.add_argument("--text_trainable", type=bool, default=False)
+    p.add_argument("--image_trainable", type=bool, default=True)
+    p.add_argument("--batch_size_train", type=int, default=128)
+    p.add_argument("--batch_size_test", type=int, default=128)
+    p.add_argument("--image_root", type=str, default="")
+    p.add_argument("--ann_root", type=str, default="")
+    p.add_argument("--image_size", type=int, default=224)
+    p.add_argument("--k_test", type=int, default=128)
+    p.add_argument("--load_npy", type=bool, default=False)
+    p.add_argument("--image_encoder", type=str, default="nfnet")
+    p.add_argument("--text_encoder", type=str, default="bert", choices=["bert", "clip"])
+    p.add_argument("--margin", default=0.2, type=float)
+    p.add_argument("--measure", default="cosine")
+    p.add_argument("--max_violation", action="store_true")
+    p.add_argument("--only_has_image_projection", type=bool, default=False)
+    p.add_argument("--grounding", type=bool, default=False)
+    p.add_argument("--distill", type=bool, default=False)
+    # additive
+    p.add_argument("--synthetic_data", type=int, default=0, metavar="STEPS_PER_EPOCH",
+                   help="train on random pairs, this many steps per epoch (no dataset offline)")
+    p.add_argument("--compute_dtype", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--seed", type=int, default=0)
+    return p
+
+
+def main(args):
+    from .engine import UnrollEngine
+    from .expert_buffer import save_expert_file
+    from .networks import VARIANTS, synthetic_expert_params
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("buffer.py needs an MI355X; the engine has no CPU path")
+    if not args.synthetic_data:
+        raise NotImplementedError(
+            "training experts on %s needs the dataset and BERT text embeddings, which are outside the "
+            "MI355X hot path (SURVEY 8f); pass --synthetic_data STEPS to exercise the pipeline" % args.dataset)
+    device = torch.device("cuda")
+    variant = VARIANTS[args.image_encoder]
+    d_txt = 768 if args.text_encoder == "bert" else 512
+    n = args.batch_train
+    eng = UnrollEngine(variant, batch=n, num_queries=n, image_size=args.image_size, d_txt=d_txt,
+                       syn_steps=1, dtype=args.compute_dtype, device=device)
+    save_dir = os.path.join(args.buffer_path, args.dataset, args.image_encoder, args.text_encoder)
+    os.makedirs(save_dir, exist_ok=True)
+    shapes_i = [s for _, s, _ in eng.param_table("img")]
+    shapes_t = [s for _, s, _ in eng.param_table("txt")]
+    g = torch.Generator(device=device).manual_seed(args.seed)
+    lr_i = torch.tensor([args.lr_teacher_img], device=device)
+    lr_t = torch.tensor([args.lr_teacher_txt], device=device)
+    from . import _lib
+    import ctypes as C
+    lib = _lib.load()
+    P = lambda t: C.c_void_p(t.data_ptr())
+    for it in range(args.num_experts):
+        th_i, th_t = synthetic_expert_params(eng, args.seed * 100003 + it, device=device)
+        snaps_i, snaps_t = [th_i.cpu()], [th_t.cpu()]          # buffer.py:67-68
+        for e in range(args.train_epochs):
+            for _ in range(args.synthetic_data):
+                img = torch.randn(n, 3, args.image_size, args.image_size, device=device, generator=g)
+                txt = torch.randn(n, d_txt, device=device, generator=g) * 0.5253
+                x = eng.img_forward(0, th_i, img)
+                y = eng.txt_forward(0, th_t, txt)
+                _, xb, yb, _ = eng.contrastive(x, y, 1.0 / 0.07)   # networks.py:878
+                gi = eng.img_backward(0, th_i, xb)
+                gt = eng.txt_backward(0, th_t, yb)
+                st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                _lib.check(lib.mdd_flat_axpy(P(th_i), P(th_i), P(gi), P(lr_i), -1.0, th_i.numel(), st))
+                _lib.check(lib.mdd_flat_axpy(P(th_t), P(th_t), P(gt), P(lr_t), -1.0, th_t.numel(), st))
+            snaps_i.append(th_i.cpu()), snaps_t.append(th_t.cpu())   # buffer.py:94-95
+        k = 0
+        while os.path.exists(os.path.join(save_dir, "img_replay_buffer_%d.pt" % k)):
+            k += 1
+        print("Saving {}".format(os.path.join(save_dir, "img_replay_buffer_%d.pt" % k)))
+        save_expert_file(os.path.join(save_dir, "img_replay_buffer_%d.pt" % k),
+                         torch.stack(snaps_i)[None], shapes_i)
+        save_expert_file(os.path.join(save_dir, "txt_replay_buffer_%d.pt" % k),
+                         torch.stack(snaps_t)[None], shapes_t)
+    eng.close()
+
+
+if __name__ == "__main__":
+    main(build_parser().parse_args())

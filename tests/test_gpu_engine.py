@@ -131,7 +131,7 @@ def test_image_passes(setup, report):
                                  mul=1.0)
 
     def G(t, ybar):
-        xi = img[idx].clone().requires_grad_(True)
+        xi = img[idx].clone()
         out, vjp = torch.func.vjp(lambda tt, xx: fi(xx, flat_param=tt), t, xi)
         return vjp(ybar)
     (_, _), (h_ref, dx_ref) = torch.func.jvp(G, (th, yb), (v, ybd))
