@@ -180,7 +180,23 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
     __syncthreads();
   }
 
-  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // ---- epilogue.  The accumulators (C/D map of the 32x32 MFMA: col = lane&31,
+  // row = (r&3) + 8*(r>>2) + 4*(lane>>5)) are transposed through this wave's LDS region so that
+  // every lane owns one 16-byte chunk of consecutive channels: all epilogue reads (bias, stashed
+  // c / c_t / a-bar, residual adds) and all stores are 16-byte vector accesses on full NHWC rows.
+  constexpr int WROWS = TM * 32, WCOLS = TN * 32, PITCH = WCOLS + 4;
+  constexpr int LPR = WCOLS / CE;      // lanes per output row
+  constexpr int RPP = 64 / LPR;        // rows per pass
+  float* stage = (float*)smem + wave * (WROWS * PITCH);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + j * 32 + l31] = acc[i][j][r];
+  __syncthreads();
+
   const ConvEpi& E = p.ep;
   AT* out_raw = (AT*)E.out_raw;
   AT* out_act = (AT*)E.out_act;
@@ -189,56 +205,70 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
   const AT* Ab = (const AT*)E.abar;
   const AT* add1 = (const AT*)E.add1;
   const AT* add2 = (const AT*)E.add2;
+  const int lrow = lane / LPR, lcol = (lane % LPR) * CE;
+  const int n = n0 + wn * WCOLS + lcol;
+  if (n < G.nc) {
+    const int ch = grp * G.nc + n;
+    float bias[CE];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    int n = n0 + (wn * TN + j) * 32 + l31;
-    if (n >= G.nc) continue;
-    int ch = grp * G.nc + n;
-    float bias = 0.f;
-    if (E.mode == EPI_FWD && E.bias) bias = E.bias[ch];
-    if (E.mode == EPI_FWD_T && E.bias_t) bias = E.bias_t[ch];
+    for (int e = 0; e < CE; ++e) bias[e] = 0.f;
+    const float* bp = E.mode == EPI_FWD ? E.bias : (E.mode == EPI_FWD_T ? E.bias_t : nullptr);
+    if (bp) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m >= p.M) continue;
-        size_t idx = (size_t)m * G.co_tot + ch;
-        float v = acc[i][j][r] + bias;
-        if (add1) v += to_f(add1[idx]);
-        switch (E.mode) {
-          case EPI_FWD:
-            if (out_raw) out_raw[idx] = from_f<AT>(v);
-            if (out_act) out_act[idx] = from_f<AT>(E.beta * silu_(v));
-            break;
-          case EPI_FWD_T:
-            if (out_raw) out_raw[idx] = from_f<AT>(v);
-            if (out_act) out_act[idx] = from_f<AT>(E.beta * dsilu_(to_f(Cst[idx])) * v);
-            break;
-          case EPI_BWD: {
-            if (out_raw) out_raw[idx] = from_f<AT>(v);
-            if (out_act) {
-              float o = E.beta * dsilu_(to_f(Cst[idx])) * v;
-              if (add2) o += to_f(add2[idx]);
-              out_act[idx] = from_f<AT>(o);
-            }
-          } break;
-          case EPI_BWD_T: {
-            if (out_raw) out_raw[idx] = from_f<AT>(v);
-            Dual cd(to_f(Cst[idx]), to_f(Ct[idx]));
-            Dual ad(to_f(Ab[idx]), v);
-            float o = E.beta * (dsilu_(cd) * ad).t;
-            if (add2) o += to_f(add2[idx]);
-            out_act[idx] = from_f<AT>(o);
-          } break;
-          default:  // EPI_BWD_LIN
-            out_raw[idx] = from_f<AT>(v);
-            break;
-        }
+      for (int e = 0; e < CE; e += 4) {
+        float4 b4 = *(const float4*)(bp + ch + e);
+        bias[e] = b4.x; bias[e + 1] = b4.y; bias[e + 2] = b4.z; bias[e + 3] = b4.w;
       }
+    }
+    auto ld = [&](const AT* ptr, size_t idx, float* f) { Chunk<AT>::unpack(*(const uint4*)(ptr + idx), f); };
+    auto st = [&](AT* ptr, size_t idx, const float* f) { *(uint4*)(ptr + idx) = Chunk<AT>::pack(f); };
+#pragma unroll 2
+    for (int ps = 0; ps < WROWS / RPP; ++ps) {
+      const int row = ps * RPP + lrow;
+      const int m = m0 + wm * WROWS + row;
+      if (m >= p.M) continue;
+      const size_t idx = (size_t)m * G.co_tot + ch;
+      float v[CE], t0[CE], t1[CE], t2[CE], o[CE];
+#pragma unroll
+      for (int e = 0; e < CE; e += 4) {
+        float4 s4 = *(const float4*)(stage + row * PITCH + lcol + e);
+        v[e] = s4.x + bias[e]; v[e + 1] = s4.y + bias[e + 1];
+        v[e + 2] = s4.z + bias[e + 2]; v[e + 3] = s4.w + bias[e + 3];
+      }
+      if (add1) {
+        ld(add1, idx, t0);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) v[e] += t0[e];
+      }
+      if (out_raw) st(out_raw, idx, v);
+      if (!out_act) continue;
+      switch (E.mode) {
+        case EPI_FWD:
+#pragma unroll
+          for (int e = 0; e < CE; ++e) o[e] = E.beta * silu_(v[e]);
+          break;
+        case EPI_FWD_T:
+        case EPI_BWD:
+          ld(Cst, idx, t0);
+#pragma unroll
+          for (int e = 0; e < CE; ++e) o[e] = E.beta * dsilu_(t0[e]) * v[e];
+          break;
+        default:  // EPI_BWD_T
+          ld(Cst, idx, t0); ld(Ct, idx, t1); ld(Ab, idx, t2);
+#pragma unroll
+          for (int e = 0; e < CE; ++e) o[e] = E.beta * (dsilu_(Dual(t0[e], t1[e])) * Dual(t2[e], v[e])).t;
+          break;
+      }
+      if (add2) {
+        ld(add2, idx, t0);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) o[e] += t0[e];
+      }
+      st(out_act, idx, o);
     }
   }
 }
+
 
 template <class AT, int WGM, int WGN, int TM, int TN>
 void launch_cfg(const KArgs& a, hipStream_t st) {
@@ -247,6 +277,8 @@ void launch_cfg(const KArgs& a, hipStream_t st) {
   k.mtiles = (a.M + BM - 1) / BM;
   k.ntiles = (a.g.nc + BN - 1) / BN;
   size_t shm = 2 * (BM + BN) * 128;
+  size_t shm_epi = 4 * (size_t)(TM * 32) * (TN * 32 + 4) * sizeof(float);  // per-wave transpose
+  if (shm_epi > shm) shm = shm_epi;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)k_conv_gemm<AT, WGM, WGN, TM, TN>,
