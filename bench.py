@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-launches", default=None,
+                    help="CSV path: one row per contraction launch of the instrumented iteration")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -204,6 +206,9 @@ def main():
             _lib.check(lib.mdd_engine_profile_read(eng.h, k, buf))
             kinds.append(dict(kernel=KIND_NAMES[k], launches=int(buf[0]), ms=buf[1], flops=buf[2],
                               bytes=buf[3]))
+        if args.dump_launches:
+            os.makedirs(os.path.dirname(os.path.abspath(args.dump_launches)), exist_ok=True)
+            _lib.check(lib.mdd_engine_profile_dump(eng.h, args.dump_launches.encode()))
         lib.mdd_engine_profile(eng.h, 0)
         dom = max(kinds, key=lambda d: d["ms"])
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS

@@ -150,6 +150,8 @@ int mdd_unrolled_match(mdd_engine* e, const mdd_iter_args* a, void* stream);
  * out4 = {launches, total milliseconds, algorithmic FLOPs, algorithmic bytes} since enable. */
 int mdd_engine_profile(mdd_engine* e, int enable);
 int mdd_engine_profile_read(mdd_engine* e, int kind, double* out4);
+/* one CSV row per contraction launch since enable (geometry, ms, TFLOP/s, GB/s) */
+int mdd_engine_profile_dump(mdd_engine* e, const char* path);
 
 /* ---- single-op entry points (parity tests; NHWC activations, dtype = MDD_DTYPE_*) */
 int mdd_op_conv2d(int dtype, int transposed, int nimg, int hin, int win, int cin, int cout, int k,

@@ -59,6 +59,7 @@ SIGNATURES = {
     "mdd_flat_sgd_momentum": (_I, [_P, _P, _P, _F, _F, _I, _L, _P]),
     "mdd_engine_profile": (_I, [_P, _I]),
     "mdd_engine_profile_read": (_I, [_P, _I, C.POINTER(C.c_double)]),
+    "mdd_engine_profile_dump": (_I, [_P, C.c_char_p]),
     "mdd_unrolled_match": (_I, [_P, C.POINTER(MddIterArgs), _P]),
     "mdd_op_conv2d": (_I, [_I] * 11 + [_P, _P, _P, _P, _P]),
     "mdd_op_conv2d_wgrad": (_I, [_I] * 10 + [_P, _P, _P, _P, _P]),

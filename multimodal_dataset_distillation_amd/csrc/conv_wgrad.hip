@@ -8,20 +8,17 @@
 //         consecutive lanes hit consecutive dwords (conflict-free, no transpose needed).
 //   bf16: v_mfma_f32_16x16x32_bf16 fragments are fetched with ds_read_b64_tr_b16 (the CDNA4
 //         LDS transpose read): a 16-lane group reads a 4-row x 16-col block and each lane gets one
-//         column.  Which 4-row block of the 32-row K-tile a group reads per instruction is a free
+//         column.  Which 4-row block of a 32-row K-step a group reads per instruction is a free
 //         k-permutation (same for A and B); it is chosen so the two groups of a half-wave read
 //         rows 8x..8x+3 and 8x+4..8x+7, which with the XOR swizzle below is bank-conflict-free.
+// Output tile BCO x BKP (64x128 for group width 64, 128x128 otherwise), BKM pixels per barrier,
+// LDS double-buffered with the next tile's global loads in flight during the MFMA phase.
 // The M range is split across blockIdx.y and combined with fp32 atomics (dW is zeroed by the
-// caller): per block at most 64x128 atomics per M-chunk of >= 256 pixels.
-// An optional second pair (dy2, x2) is accumulated too (tangent pass), and the bias gradient
-// (column sums of dy1) is taken from the staging registers of the k'-tile-0 blocks.
+// caller).  An optional second pair (dy2, x2) is accumulated too (tangent pass), and the bias
+// gradient (column sums of dy1) is taken from the staging registers of the k'-tile-0 blocks.
 #include "kernels.h"
 
 namespace {
-
-constexpr int BCO = 64;    // output-channel tile
-constexpr int BKP = 128;   // k' = (tap, kc) tile
-constexpr int BKM = 32;    // pixels per K-step
 
 struct WArgs {
   const void* dy1; const void* x1; const void* dy2; const void* x2;
@@ -30,28 +27,29 @@ struct WArgs {
   int M, cotiles, kptiles, mchunk;
 };
 
-template <class AT> struct WT;
-template <> struct WT<bf16> { static constexpr int CE = 8; };
-template <> struct WT<float> { static constexpr int CE = 4; };
-
 // LDS chunk swizzle (bf16 path only): rows of ROWB bytes
 template <int ROWB> DEVI int wswz(int row) { return ROWB == 128 ? ((row >> 1) & 3) : (row & 7); }
 
-template <class AT>
+template <class AT, int BCO, int BKP, int BKM>
 __global__ __launch_bounds__(256) void k_conv_wgrad(const WArgs p) {
-  constexpr int CE = WT<AT>::CE;
+  constexpr int CE = 16 / (int)sizeof(AT);
   constexpr bool BF = sizeof(AT) == 2;
   constexpr int DCH = BCO / CE, XCH = BKP / CE;          // chunks per row
   constexpr int DROWB = BCO * sizeof(AT), XROWB = BKP * sizeof(AT);
-  constexpr int DSL = (BKM * DCH) / 256 > 0 ? (BKM * DCH) / 256 : 1;  // dy chunks per thread
-  constexpr int XSL = (BKM * XCH) / 256;                              // x chunks per thread
+  constexpr int DSL = (BKM * DCH) / 256, XSL = (BKM * XCH) / 256;   // chunks per thread
+  constexpr int DSTEP = 256 / DCH, XSTEP = 256 / XCH;
   constexpr int DTILE = BKM * DROWB, XTILE = BKM * XROWB;
+  constexpr int WCO = BCO / 64, WKP = 4 / WCO;           // wave grid over (co, k')
+  constexpr int WKW = BKP / WKP;                         // k' width per wave
+  static_assert(DSL >= 1 && XSL >= 1, "tile too small for 256 threads");
+  static_assert(BF || (BCO == 64 && BKP == 128), "f32 path: 64x128 tile only");
   __shared__ __attribute__((aligned(16))) char smem[2 * (DTILE + XTILE)];
   char* Ds = smem;
   char* Xs = smem + 2 * DTILE;
 
   const ConvGeom& G = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave / WKP, wk = wave - wc * WKP;
   int bid = blockIdx.x;
   const int kpt = bid % p.kptiles; bid /= p.kptiles;
   const int cot = bid % p.cotiles;
@@ -60,19 +58,36 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const WArgs p) {
   const int ktot = G.k * G.k * G.kc;
   const int mbeg = blockIdx.y * p.mchunk;
   const int mend = min(p.M, mbeg + p.mchunk);
-  const int niter1 = (mend - mbeg + BKM - 1) / BKM;
+  const int niter1 = mend > mbeg ? (mend - mbeg + BKM - 1) / BKM : 0;
   const int niter = p.dy2 ? 2 * niter1 : niter1;
 
-  // ---- staging geometry.  dy: chunk col dcol, rows drow + (256/DCH)*i ; x: xcol, xrow + (256/XCH)*i
+  // ---- staging geometry.  dy: chunk col dcol, rows drow + DSTEP*i ; x: xcol, rows xrow + XSTEP*i
   const int dcol = tid % DCH, drow = tid / DCH;
   const int xcol = tid % XCH, xrow = tid / XCH;
-  constexpr int DSTEP = 256 / DCH, XSTEP = 256 / XCH;
   // x chunk -> (tap, kc) is iteration-invariant
   const int kp = kp0 + xcol * CE;
   const bool kp_ok = kp < ktot;
   const int tap = kp / G.kc, kcq = kp - tap * G.kc;
   const int ty = tap / G.k, tx = tap - ty * G.k;
   const bool dco_ok = (co0 + dcol * CE) < G.nc;
+  const bool pointwise = G.k == 1 && G.stride == 1 && G.pad == 0;
+  const AT* dyb = nullptr;
+  const size_t dy_col = (size_t)grp * G.nc + co0 + dcol * CE;
+  const size_t x_col = (size_t)grp * G.kc + kcq;
+
+  // running (image, oy, ox) of each x row slot; advanced by BKM pixels per iteration
+  int sox[XSL], soy[XSL], sni[XSL];
+  auto init_rows = [&]() {
+#pragma unroll
+    for (int i = 0; i < XSL; ++i) {
+      int m = mbeg + xrow + XSTEP * i;
+      sox[i] = m % G.wo;
+      int t = m / G.wo;
+      soy[i] = t % G.ho;
+      sni[i] = t / G.ho;
+    }
+  };
+  if (!pointwise) init_rows();
 
   uint4 rd[DSL], rx[XSL];
   float bsum[CE];
@@ -84,12 +99,13 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const WArgs p) {
     const bool second = it >= niter1;
     const AT* DY = (const AT*)(second ? p.dy2 : p.dy1);
     const AT* X = (const AT*)(second ? p.x2 : p.x1);
+    if (it == niter1 && !pointwise) init_rows();
     const int mb = mbeg + (second ? it - niter1 : it) * BKM;
 #pragma unroll
     for (int i = 0; i < DSL; ++i) {
       int m = mb + drow + DSTEP * i;
-      if (m < mend && dco_ok && (drow + DSTEP * i) < BKM) {
-        rd[i] = *(const uint4*)(DY + (size_t)m * G.co_tot + grp * G.nc + co0 + dcol * CE);
+      if (m < mend && dco_ok) {
+        rd[i] = *(const uint4*)(DY + (size_t)m * G.co_tot + dy_col);
         if (do_bias && !second) {
           float f[CE];
           Chunk<AT>::unpack(rd[i], f);
@@ -104,18 +120,17 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const WArgs p) {
     for (int i = 0; i < XSL; ++i) {
       int m = mb + xrow + XSTEP * i;
       bool ok = kp_ok && m < mend;
-      if (ok) {
-        int ox = m % G.wo;
-        int t = m / G.wo;
-        int oy = t % G.ho;
-        int ni = t / G.ho;
-        int iy = oy * G.stride - G.pad + ty, ix = ox * G.stride - G.pad + tx;
-        ok = (unsigned)iy < (unsigned)G.ha && (unsigned)ix < (unsigned)G.wa;
-        if (ok)
-          rx[i] = *(const uint4*)(X + ((size_t)(ni * G.ha + iy) * G.wa + ix) * G.ca_tot +
-                                  grp * G.kc + kcq);
+      size_t pix = (size_t)m;
+      if (!pointwise) {
+        int iy = soy[i] * G.stride - G.pad + ty, ix = sox[i] * G.stride - G.pad + tx;
+        ok = ok && (unsigned)iy < (unsigned)G.ha && (unsigned)ix < (unsigned)G.wa;
+        pix = (size_t)(sni[i] * G.ha + iy) * G.wa + ix;
+        // advance this slot to the next iteration's pixel
+        sox[i] += BKM;
+        while (sox[i] >= G.wo) { sox[i] -= G.wo; ++soy[i]; }
+        while (soy[i] >= G.ho) { soy[i] -= G.ho; ++sni[i]; }
       }
-      if (!ok) rx[i] = make_uint4(0, 0, 0, 0);
+      rx[i] = ok ? *(const uint4*)(X + pix * G.ca_tot + x_col) : make_uint4(0, 0, 0, 0);
     }
   };
   auto store_tile = [&](int buf) {
@@ -124,10 +139,8 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const WArgs p) {
 #pragma unroll
     for (int i = 0; i < DSL; ++i) {
       int r = drow + DSTEP * i;
-      if (r < BKM) {
-        int c = BF ? (dcol ^ (wswz<DROWB>(r) << 1)) : dcol;
-        *(uint4*)(d + r * DROWB + c * 16) = rd[i];
-      }
+      int c = BF ? (dcol ^ (wswz<DROWB>(r) << 1)) : dcol;
+      *(uint4*)(d + r * DROWB + c * 16) = rd[i];
     }
 #pragma unroll
     for (int i = 0; i < XSL; ++i) {
@@ -138,9 +151,10 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const WArgs p) {
   };
 
   // accumulators: f32 -> 2 blocks of 32x32 (co 0..31, 32..63) x (32 k' of this wave)
-  //               bf16 -> 4x2 blocks of 16x16
+  //               bf16 -> 4 x (WKW/16) blocks of 16x16 (64 co x WKW k' per wave)
+  constexpr int NBK = BF ? WKW / 16 : 1;
   f32x16 accf[2];
-  f32x4 accb[4][2];
+  f32x4 accb[4][NBK];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -148,7 +162,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const WArgs p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NBK; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) accb[i][j][r] = 0.f;
 
@@ -170,42 +184,45 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const WArgs p) {
         int r = 2 * t + lh;
         float a0 = *(const float*)(d + r * DROWB + l31 * 4);
         float a1 = *(const float*)(d + r * DROWB + (32 + l31) * 4);
-        float b = *(const float*)(x + r * XROWB + (wave * 32 + l31) * 4);
+        float b = *(const float*)(x + r * XROWB + (wk * 32 + l31) * 4);
         accf[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, accf[0], 0, 0, 0);
         accf[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, accf[1], 0, 0, 0);
       }
     } else {
       const int gq = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
-      // 4-row block read by this lane group in instruction e: rho(g,e) = 2*(2e + (g>>1)) + (g&1)
-      s16x4 af[4][2], bfr[2][2];
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        int row = 4 * (2 * (2 * e + (gq >> 1)) + (gq & 1)) + q;
+      for (int ks = 0; ks < BKM / 32; ++ks) {
+        // 4-row block read by this lane group in instruction e: rho(g,e) = 2*(2e + (g>>1)) + (g&1)
+        s16x4 af[4][2], bfr[NBK][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          int unit = (16 * i + 4 * pp) >> 2;  // 8-byte unit index within the row
-          int u = unit ^ (wswz<DROWB>(row) << 2);
-          af[i][e] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)(d + row * DROWB + u * 8));
+        for (int e = 0; e < 2; ++e) {
+          int row = ks * 32 + 4 * (2 * (2 * e + (gq >> 1)) + (gq & 1)) + q;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            int unit = (wc * 64 + 16 * i + 4 * pp) >> 2;  // 8-byte unit index within the row
+            int u = unit ^ (wswz<DROWB>(row) << 2);
+            af[i][e] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(d + row * DROWB + u * 8));
+          }
+#pragma unroll
+          for (int j = 0; j < NBK; ++j) {
+            int unit = (wk * WKW + 16 * j + 4 * pp) >> 2;
+            int u = unit ^ (wswz<XROWB>(row) << 2);
+            bfr[j][e] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(x + row * XROWB + u * 8));
+          }
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          int unit = (wave * 32 + 16 * j + 4 * pp) >> 2;
-          int u = unit ^ (wswz<XROWB>(row) << 2);
-          bfr[j][e] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)(x + row * XROWB + u * 8));
-        }
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NBK; ++j) {
+            s16x8 a8 = __builtin_shufflevector(af[i][0], af[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
+            s16x8 b8 = __builtin_shufflevector(bfr[j][0], bfr[j][1], 0, 1, 2, 3, 4, 5, 6, 7);
+            accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, a8), __builtin_bit_cast(bf16x8, b8), accb[i][j], 0, 0, 0);
+          }
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          typedef __attribute__((ext_vector_type(8))) short s16x8;
-          s16x8 a8 = __builtin_shufflevector(af[i][0], af[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
-          s16x8 b8 = __builtin_shufflevector(bfr[j][0], bfr[j][1], 0, 1, 2, 3, 4, 5, 6, 7);
-          accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-              __builtin_bit_cast(bf16x8, a8), __builtin_bit_cast(bf16x8, b8), accb[i][j], 0, 0, 0);
-        }
     }
     if (it + 1 < niter) store_tile(buf ^ 1);
     __syncthreads();
@@ -215,7 +232,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const WArgs p) {
   float* dWg = p.dW + (size_t)grp * G.nc * ktot;
   if constexpr (!BF) {
     const int l31 = lane & 31, lh = lane >> 5;
-    int kcol = kp0 + wave * 32 + l31;
+    int kcol = kp0 + wk * 32 + l31;
     if (kcol < ktot) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -228,14 +245,14 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const WArgs p) {
   } else {
     const int gq = lane >> 4, li = lane & 15;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int kcol = kp0 + wave * 32 + 16 * j + li;
+    for (int j = 0; j < NBK; ++j) {
+      int kcol = kp0 + wk * WKW + 16 * j + li;
       if (kcol >= ktot) continue;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          int co = co0 + 16 * i + 4 * gq + r;
+          int co = co0 + wc * 64 + 16 * i + 4 * gq + r;
           if (co < G.nc) atomicAdd(dWg + (size_t)co * ktot + kcol, accb[i][j][r]);
         }
     }
@@ -255,6 +272,26 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const WArgs p) {
       if (co0 + tid < G.nc) atomicAdd(p.dbias + grp * G.nc + co0 + tid, s);
     }
   }
+  (void)dyb;
+}
+
+template <class AT, int BCO, int BKP, int BKM>
+void launch_cfg(WArgs a, hipStream_t st) {
+  const ConvGeom& g = a.g;
+  int ktot = g.k * g.k * g.kc;
+  a.cotiles = (g.nc + BCO - 1) / BCO;
+  a.kptiles = (ktot + BKP - 1) / BKP;
+  int tiles = a.cotiles * a.kptiles * g.groups;
+  int splits = (1024 + tiles - 1) / tiles;
+  int maxsplits = (a.M + 4 * BKM - 1) / (4 * BKM);
+  if (splits > maxsplits) splits = maxsplits;
+  if (splits < 1) splits = 1;
+  int mchunk = (a.M + splits - 1) / splits;
+  mchunk = ((mchunk + BKM - 1) / BKM) * BKM;
+  splits = (a.M + mchunk - 1) / mchunk;
+  a.mchunk = mchunk;
+  dim3 grid(tiles, splits);
+  k_conv_wgrad<AT, BCO, BKP, BKM><<<grid, 256, 0, st>>>(a);
 }
 
 }  // namespace
@@ -266,20 +303,13 @@ void launch_conv_wgrad(const ConvGeom& g, const AT* dy1, const AT* x1, const AT*
   a.dy1 = dy1; a.x1 = x1; a.dy2 = dy2; a.x2 = x2; a.dW = dW; a.dbias = dbias;
   a.g = g;
   a.M = g.nimg * g.ho * g.wo;
-  int ktot = g.k * g.k * g.kc;
-  a.cotiles = (g.nc + BCO - 1) / BCO;
-  a.kptiles = (ktot + BKP - 1) / BKP;
-  int tiles = a.cotiles * a.kptiles * g.groups;
-  int splits = (1536 + tiles - 1) / tiles;
-  int maxsplits = (a.M + 255) / 256;
-  if (splits > maxsplits) splits = maxsplits;
-  if (splits < 1) splits = 1;
-  int mchunk = (a.M + splits - 1) / splits;
-  mchunk = ((mchunk + BKM - 1) / BKM) * BKM;
-  splits = (a.M + mchunk - 1) / mchunk;
-  a.mchunk = mchunk;
-  dim3 grid(tiles, splits);
-  k_conv_wgrad<AT><<<grid, 256, 0, st>>>(a);
+  a.cotiles = a.kptiles = a.mchunk = 0;
+  if constexpr (sizeof(AT) == 2) {
+    if (g.nc > 64) launch_cfg<AT, 128, 128, 64>(a, st);
+    else launch_cfg<AT, 64, 128, 64>(a, st);
+  } else {
+    launch_cfg<AT, 64, 128, 32>(a, st);
+  }
 }
 template void launch_conv_wgrad<float>(const ConvGeom&, const float*, const float*, const float*,
                                        const float*, float*, float*, hipStream_t);

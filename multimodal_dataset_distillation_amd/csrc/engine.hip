@@ -126,6 +126,7 @@ struct mdd_engine {
   virtual int unrolled_match(const mdd_iter_args* a, hipStream_t st) = 0;
   virtual void profile_enable(bool on) = 0;
   virtual int profile_read(int kind, double* out4) = 0;
+  virtual int profile_dump(const char* path) = 0;
   std::vector<ParamInfo> pimg, ptxt;
   int64_t P_img = 0, P_txt = 0;
   int feat = 0;
@@ -417,7 +418,7 @@ struct Eng : mdd_engine {
   }
 
   // ---- optional HIP-event timing of every contraction launch (bench.py roofline accounting)
-  struct Prof { int kind; double flops, bytes; hipEvent_t a, b; };
+  struct Prof { int kind; double flops, bytes; hipEvent_t a, b; ConvGeom g; int ns; };
   bool prof_on = false;
   std::vector<Prof> prof;
   void profile_enable(bool on) override {
@@ -430,6 +431,19 @@ struct Eng : mdd_engine {
       float ms = 0; HIP_CHECK_RET(hipEventSynchronize(p.b)); HIP_CHECK_RET(hipEventElapsedTime(&ms, p.a, p.b));
       out[0] += 1; out[1] += ms; out[2] += p.flops; out[3] += p.bytes;
     }
+    return 0;
+  }
+  int profile_dump(const char* path) override {
+    FILE* f = fopen(path, "w");
+    if (!f) return mdd_set_error_msg(4, "mdd: cannot open profile dump file");
+    fprintf(f, "kind,transposed,nsrc,M,nc,groups,kc,k,stride,ha,ho,ms,gflops,gbytes,tflops_s,gb_s\n");
+    for (auto& p : prof) {
+      float ms = 0; hipEventSynchronize(p.b); hipEventElapsedTime(&ms, p.a, p.b);
+      fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.3f,%.4f,%.1f,%.1f\n", p.kind, p.g.transposed,
+              p.ns, p.g.nimg * p.g.ho * p.g.wo, p.g.nc, p.g.groups, p.g.kc, p.g.k, p.g.stride, p.g.ha,
+              p.g.ho, ms, p.flops / 1e9, p.bytes / 1e9, p.flops / ms / 1e9, p.bytes / ms / 1e6);
+    }
+    fclose(f);
     return 0;
   }
   double conv_macs(const ConvL& L) const {
@@ -449,7 +463,7 @@ struct Eng : mdd_engine {
     hipEventRecord(p.a, st);
     launch_conv_gemm<AT>(g, A1, B1, A2, B2, e, st);
     hipEventRecord(p.b, st);
-    prof.push_back(p);
+    p.g = g; p.ns = ns; prof.push_back(p);
   }
   void wgrad(const ConvL& L, const ConvGeom& g, const AT* dy1, const AT* x1, const AT* dy2, const AT* x2,
              float* dW, float* db, hipStream_t st) {
@@ -463,7 +477,7 @@ struct Eng : mdd_engine {
     hipEventRecord(p.a, st);
     launch_conv_wgrad<AT>(g, dy1, x1, dy2, x2, dW, db, st);
     hipEventRecord(p.b, st);
-    prof.push_back(p);
+    p.g = g; p.ns = ns; prof.push_back(p);
   }
 
   // c = conv(in) + bias ; C <- c ; A <- beta*silu(c).   T: tangent of the same (primal from stash)
@@ -945,6 +959,10 @@ int mdd_engine_profile(mdd_engine* e, int enable) {
   CHECK_ARG(e, "null engine");
   e->profile_enable(enable != 0);
   return 0;
+}
+int mdd_engine_profile_dump(mdd_engine* e, const char* path) {
+  CHECK_ARG(e && path, "profile_dump");
+  return e->profile_dump(path);
 }
 int mdd_engine_profile_read(mdd_engine* e, int kind, double* out4) {
   CHECK_ARG(e && out4 && kind >= 0 && kind < 4, "profile_read");
