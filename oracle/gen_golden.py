@@ -89,7 +89,7 @@ def gen_text_only(ReparamModule, RefHead, path):
     """Pinned 100% by reference code: ReparamModule(ProjectionHead) + the loop, image features
     held constant.  Covers SURVEY 8a rows a4,a6,a7,a8(txt),a9,a10,a11(txt)."""
     torch.manual_seed(11)
-    n, d_in, d_out, K = 6, 32, 64, 3
+    n, d_in, d_out, K = 6, 32, 288, 3   # d_out = feature dim of the nfnet_tiny engine
     head = RefHead(d_in, d_out, dropout=0.0)
     with torch.no_grad():
         head.layer_norm.weight.add_(0.1 * torch.randn(d_out))
@@ -98,11 +98,19 @@ def gen_text_only(ReparamModule, RefHead, path):
     net = ReparamModule(head)
     net.train()
     th0 = net.flat_param.detach().clone()
-    tgt = th0 + 0.02 * torch.randn_like(th0)
     text_syn = (torch.randn(n, d_in) * 0.5253 - 0.0094).requires_grad_(True)
     lr_img = torch.tensor(0.7, requires_grad=True)   # doubles as logit scale (distill.py:548)
     lr_txt = torch.tensor(0.3, requires_grad=True)
     xs = [torch.randn(n, d_out) for _ in range(K)]
+    # expert displacement with the norm of the student's own K-step move (loss ratio is O(1)-sensitive)
+    a0 = th0.clone().requires_grad_(True)
+    y0 = net(text_syn.detach(), flat_param=a0)
+    y0 = y0 / y0.norm(dim=1, keepdim=True)
+    x0 = xs[0] / xs[0].norm(dim=1, keepdim=True)
+    lg = 0.7 * x0 @ y0.t()
+    l0 = (F.cross_entropy(lg, torch.arange(n)) + F.cross_entropy(lg.t(), torch.arange(n))) / 2
+    g0, = torch.autograd.grad(l0, a0)
+    tgt = th0 + float(0.3 * K * g0.norm() / th0.numel() ** 0.5) * torch.randn_like(th0)
     perms = [torch.randperm(n) for _ in range(K)]
     grand, _, txt_loss, ces, _, thK = ref_loop(None, net, None, text_syn, lr_img, lr_txt, None,
                                               th0, None, tgt, perms, fixed_x=xs)

@@ -1,0 +1,136 @@
+"""GPU parity of the DROP-IN surface: the reference's loop (distill.py:509-606) run verbatim through
+`ReparamModule(module)(x, flat_param=theta)` + `torch.autograd.grad(create_graph=True)` +
+`backward()`, with every network FLOP in libmdd_hip.so, against the committed goldens; the
+text-only golden (pinned 100% by reference code); and BASELINE config 1 (N=10, syn_steps=2,
+NFNet-l0, 224x224, fp32) against its golden scalars."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _loaded_native_lib():
+    with open("/proc/self/maps") as f:
+        return any("libmdd_hip.so" in line for line in f)
+
+
+def test_autograd_dropin_matches_golden_tiny(report):
+    from multimodal_dataset_distillation_amd import networks as nw
+    from multimodal_dataset_distillation_amd.distill import reference_loop_iteration
+    from multimodal_dataset_distillation_amd.reparam_module import ReparamModule
+    g = np.load(os.path.join(GOLDEN, "unroll_tiny.npz"))
+    n, size, d_txt, K = int(g["n"]), int(g["size"]), int(g["d_txt"]), int(g["K"])
+    dev = "cuda"
+    enc = nw.ImageEncoder(variant="nfnet_tiny", dtype="f32")
+    enc.syn_steps, enc.d_txt = K, d_txt
+    head = nw.ProjectionHead(d_txt, enc.num_features, dropout=0.0, image_size=size,
+                             variant="nfnet_tiny", syn_steps=K, dtype="f32")
+    img_net, txt_net = ReparamModule(enc).to(dev), ReparamModule(head).to(dev)
+    img_net.train(), txt_net.train()
+    assert img_net.param_numel == g["theta0_img"].size and txt_net.param_numel == g["theta0_txt"].size
+    T = lambda k: torch.from_numpy(g[k]).to(dev)
+    image_syn = T("image_syn0").requires_grad_(True)
+    text_syn = T("text_syn0").requires_grad_(True)
+    lri = torch.tensor(0.1, device=dev, requires_grad=True)
+    lrt = torch.tensor(0.1, device=dev, requires_grad=True)
+    perms = [torch.from_numpy(p).to(dev) for p in g["perms"][0]]
+    grand, il, tl, ces = reference_loop_iteration(img_net, txt_net, image_syn, text_syn, lri, lrt,
+                                                  T("theta0_img"), T("theta0_txt"), T("target_img"),
+                                                  T("target_txt"), perms)
+    grand.backward()                                   # reference distill.py:606
+    e = dict(grand=abs(grand.item() - g["it0_grand"]) / abs(g["it0_grand"]),
+             ces=rel_err(torch.stack(ces), torch.from_numpy(g["it0_ces"])),
+             g_img=rel_err(image_syn.grad, torch.from_numpy(g["it0_g_image_syn"])),
+             g_txt=rel_err(text_syn.grad, torch.from_numpy(g["it0_g_text_syn"])),
+             g_lri=abs(lri.grad.item() - g["it0_g_lr_img"]) / abs(g["it0_g_lr_img"]),
+             g_lrt=abs(lrt.grad.item() - g["it0_g_lr_txt"]) / abs(g["it0_g_lr_txt"]))
+    report("autograd drop-in (ReparamModule + torch.autograd over HIP ops) vs golden tiny: "
+           + " ".join(f"{k} {float(v):.2e}" for k, v in e.items()))
+    assert all(float(v) < 1e-3 for v in e.values()), e
+    assert _loaded_native_lib()
+    nw.release_engines()
+
+
+def test_text_only_golden_through_hip_ops(report):
+    """tests/golden/text_only_unroll.npz is produced entirely by reference code
+    (ReparamModule(ProjectionHead) + the distill.py loop with constant image features)."""
+    from multimodal_dataset_distillation_amd import functional as Fn
+    from multimodal_dataset_distillation_amd.engine import UnrollEngine
+    g = np.load(os.path.join(GOLDEN, "text_only_unroll.npz"))
+    n, d_in, d_out, K = int(g["n"]), int(g["d_in"]), int(g["d_out"]), int(g["K"])
+    dev = "cuda"
+    eng = UnrollEngine("nfnet_tiny", batch=n, num_queries=n, image_size=32, d_txt=d_in, syn_steps=K,
+                       dtype="f32")
+    assert eng.feature_dim == d_out and eng.P_txt == g["theta0"].size
+    T = lambda k: torch.from_numpy(g[k]).to(dev)
+    th0, tgt = T("theta0"), T("target")
+    text = T("text_syn").requires_grad_(True)
+    s = torch.tensor(float(g["lr_img"]), device=dev, requires_grad=True)
+    lrt = torch.tensor(float(g["lr_txt"]), device=dev, requires_grad=True)
+    tp = [th0.clone().requires_grad_(True)]
+    ces = []
+    for k in range(K):
+        idx = torch.from_numpy(g["perms"][k]).to(dev)
+        y = Fn.text_projection(eng, k, tp[-1], text[idx])
+        loss = Fn.contrastive_loss(eng, T("xs")[k], y, s)
+        ces.append(loss.detach())
+        tg = torch.autograd.grad(loss, tp[-1], create_graph=True)[0]
+        tp.append(tp[-1] - lrt * tg)
+    grand = F.mse_loss(tp[-1], tgt, reduction="sum") / F.mse_loss(th0, tgt, reduction="sum")
+    gt, gs, gl = torch.autograd.grad(grand, [text, s, lrt])
+    e = dict(grand=abs(grand.item() - float(g["grand"])) / float(g["grand"]),
+             ces=rel_err(torch.stack(ces), torch.from_numpy(g["ces"])),
+             thK=rel_err(tp[-1], torch.from_numpy(g["theta_K"])),
+             g_txt=rel_err(gt, torch.from_numpy(g["g_text_syn"])),
+             g_s=abs(gs.item() - float(g["g_lr_img"])) / abs(float(g["g_lr_img"])),
+             g_lr=abs(gl.item() - float(g["g_lr_txt"])) / abs(float(g["g_lr_txt"])))
+    report("text-only golden (reference ReparamModule+ProjectionHead) via HIP ops: "
+           + " ".join(f"{k} {float(v):.2e}" for k, v in e.items()))
+    assert all(float(v) < 1e-3 for v in e.values()), e
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_config1_golden_scalars(dtype, report):
+    """BASELINE configs[0]: N=10, syn_steps=2, NFNet-l0 + 768-d text, 224x224.  theta0 / targets are
+    regenerated from the golden's seeds with the oracle constructors (torch CPU RNG)."""
+    from multimodal_dataset_distillation_amd.engine import UnrollEngine
+    from oracle import distill_ref as dr, nfnet_ref as nr
+    g = np.load(os.path.join(GOLDEN, "unroll_c1_scalars.npz"))
+    n, size, d_txt, K, seed = int(g["n"]), int(g["size"]), int(g["d_txt"]), int(g["K"]), int(g["seed"])
+    torch.manual_seed(seed)
+    enc = nr.ImageEncoder(str(g["variant"]))
+    nr.randomize_like_trained(enc, seed + 1)
+    head = dr.ProjectionHead(d_txt, enc.model.num_features)     # same RNG draws as the reference's
+    th0i, th0t = dr.FlatModule(enc).flat_param(), dr.FlatModule(head).flat_param()
+    gen = torch.Generator().manual_seed(seed + 2)
+    tgi = th0i + float(g["sig_img"]) * torch.randn(th0i.shape, generator=gen)
+    tgt = th0t + float(g["sig_txt"]) * torch.randn(th0t.shape, generator=gen)
+    img, txt = dr.synthetic_inputs(n, size, d_txt, seed=seed + 3)
+    assert np.allclose(img[:, :, :4, :4].numpy(), g["image_syn0"]) and np.allclose(txt.numpy(), g["text_syn0"])
+    dev = "cuda"
+    eng = UnrollEngine(str(g["variant"]), batch=n, num_queries=n, image_size=size, d_txt=d_txt,
+                       syn_steps=K, dtype=dtype)
+    lr = torch.tensor([0.1, 0.1], device=dev)
+    out = eng.unrolled_match(img.to(dev), txt.to(dev), lr[0:1], lr[1:2], th0i.to(dev), th0t.to(dev),
+                             tgi.to(dev), tgt.to(dev), perms=torch.from_numpy(g["perms"][0]).to(dev))
+    torch.cuda.synchronize()
+    gi = out["image_syn"].cpu()
+    e = dict(grand=abs(out["grand_loss"].item() - g["it0_grand"]) / abs(g["it0_grand"]),
+             img_loss=abs(out["img_loss"].item() - g["it0_img_loss"]) / abs(g["it0_img_loss"]),
+             ces=rel_err(out["contrastive"], torch.from_numpy(g["it0_ces"])),
+             g_img_slice=rel_err(gi[:, :, ::37, ::41], torch.from_numpy(g["it0_g_image_syn_slice"])),
+             g_img_norm=abs(gi.norm().item() - g["it0_g_image_syn_norm"]) / g["it0_g_image_syn_norm"],
+             g_txt=rel_err(out["text_syn"], torch.from_numpy(g["it0_g_text_syn"])),
+             g_lri=abs(out["lr"][0].item() - g["it0_g_lr_img"]) / abs(g["it0_g_lr_img"]),
+             g_lrt=abs(out["lr"][1].item() - g["it0_g_lr_txt"]) / abs(g["it0_g_lr_txt"]))
+    report(f"config-1 golden scalars {dtype}: " + " ".join(f"{k} {float(v):.2e}" for k, v in e.items()))
+    tol = 1e-3 if dtype == "f32" else 1e-1
+    assert all(float(v) < tol for v in e.values()), e
+    eng.close()

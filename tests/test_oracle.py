@@ -1,0 +1,128 @@
+"""CPU tests of the oracle (the checker itself): structural anchors of the NFNet restatement, the
+restated loop against the committed golden fixtures (which were produced with the reference's own
+ReparamModule + ProjectionHead, oracle/gen_golden.py), optimiser semantics, and -- when the
+reference checkout is present (build container only) -- the restatement against the reference's
+importable pieces directly."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, rel_err
+from oracle import distill_ref as dr
+from oracle import nfnet_ref as nr
+
+REF = "/root/reference"
+
+
+def test_nfnet_l0_structural_anchors():
+    m = nr.ImageEncoder("nfnet_l0")
+    fm = dr.FlatModule(m)
+    assert fm.param_numel == 32_769_488            # + 2304*1000+1000 head = 35,074,488 (timm: 35.07 M)
+    assert fm.param_numel + 2304 * 1000 + 1000 == 35_074_488
+    assert m.model.num_features == 2304            # reference networks.py:811
+    assert len(fm.names) == 57 * 3 + 12 * 4       # 57 ScaledStdConv2d (w,b,gain) + 12 SE (fc1,fc2 w,b)
+    assert fm.names[:3] == ["model.stem.conv1.weight", "model.stem.conv1.bias", "model.stem.conv1.gain"]
+    assert fm.names[-3:] == ["model.final_conv.weight", "model.final_conv.bias", "model.final_conv.gain"]
+    # first block of stage 1: downsample.conv -> conv1 -> conv2 -> conv2b -> conv3 -> attn_last
+    blk = [n for n in fm.names if n.startswith("model.stages.1.0.")]
+    order = [n.split(".")[4] for n in blk]
+    assert order[:3] == ["downsample"] * 3 and order[-4:] == ["attn_last"] * 4
+    assert dr.FlatModule(dr.ProjectionHead(768, 2304)).param_numel == 7_087_104
+    with torch.no_grad():
+        y = m(torch.randn(1, 3, 224, 224))
+    assert y.shape == (1, 2304)
+
+
+def test_weight_standardisation_matches_definition():
+    conv = nr.ScaledStdConv2d(8, 16, 3, gamma=nr.GAMMA_SILU, eps=1e-5)
+    with torch.no_grad():
+        conv.gain.copy_(torch.randn_like(conv.gain))
+    w = conv.weight.detach()
+    mu = w.mean((1, 2, 3), keepdim=True)
+    var = w.var((1, 2, 3), unbiased=False, keepdim=True)
+    ref = (w - mu) * torch.rsqrt(var + 1e-5) * conv.gain * (nr.GAMMA_SILU * (8 * 9) ** -0.5)
+    assert torch.allclose(conv.standardized_weight(), ref, atol=1e-6)
+
+
+def test_sgd_momentum_matches_torch():
+    p0, g1, g2 = torch.randn(50), torch.randn(50), torch.randn(50)
+    q = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([q], lr=1000.0, momentum=0.5)
+    mine, sgd = p0.clone(), dr.SGDMomentum(1000.0, 0.5)
+    for g in (g1, g2):
+        q.grad = g.clone()
+        opt.step()
+        mine = sgd.step(mine, g)
+    assert torch.allclose(mine, q.detach(), rtol=1e-6, atol=1e-4)
+
+
+def test_restated_loop_matches_golden_text_only():
+    """golden produced by the reference's ReparamModule(ProjectionHead) + the distill.py loop."""
+    g = np.load(os.path.join(GOLDEN, "text_only_unroll.npz"))
+    n, d_in, d_out, K = int(g["n"]), int(g["d_in"]), int(g["d_out"]), int(g["K"])
+    ft = dr.FlatModule(dr.ProjectionHead(d_in, d_out))
+    th0, tgt = torch.from_numpy(g["theta0"]), torch.from_numpy(g["target"])
+    text = torch.from_numpy(g["text_syn"]).requires_grad_(True)
+    s = torch.tensor(float(g["lr_img"]), requires_grad=True)
+    lrt = torch.tensor(float(g["lr_txt"]), requires_grad=True)
+    tp = [th0.clone().requires_grad_(True)]
+    for k in range(K):
+        idx = torch.from_numpy(g["perms"][k])
+        y = ft(text[idx], flat_param=tp[-1])
+        loss = dr.contrastive_loss(torch.from_numpy(g["xs"][k]), y, s)
+        assert abs(loss.item() - g["ces"][k]) < 1e-6
+        tg = torch.autograd.grad(loss, tp[-1], create_graph=True)[0]
+        tp.append(tp[-1] - lrt * tg)
+    grand = F.mse_loss(tp[-1], tgt, reduction="sum") / F.mse_loss(th0, tgt, reduction="sum")
+    gt, gs, gl = torch.autograd.grad(grand, [text, s, lrt])
+    assert abs(grand.item() - float(g["grand"])) < 1e-6
+    assert rel_err(gt, torch.from_numpy(g["g_text_syn"])) < 1e-5
+    assert abs(gs.item() - float(g["g_lr_img"])) < 1e-5 * abs(float(g["g_lr_img"])) + 1e-9
+    assert abs(gl.item() - float(g["g_lr_txt"])) < 1e-5 * abs(float(g["g_lr_txt"])) + 1e-9
+
+
+def test_restated_loop_matches_golden_tiny_two_iterations():
+    g = np.load(os.path.join(GOLDEN, "unroll_tiny.npz"))
+    n, size, d_txt, K = int(g["n"]), int(g["size"]), int(g["d_txt"]), int(g["K"])
+    enc = nr.ImageEncoder(str(g["variant"]))
+    fi = dr.FlatModule(enc)
+    ft = dr.FlatModule(dr.ProjectionHead(d_txt, enc.model.num_features))
+    T = lambda k: torch.from_numpy(g[k])
+    img, txt = T("image_syn0").clone(), T("text_syn0").clone()
+    lr = torch.tensor([0.1, 0.1])
+    opt = [dr.SGDMomentum(1000.0), dr.SGDMomentum(1000.0), dr.SGDMomentum(1e-3)]
+    for it in range(2):
+        ir, tr = img.clone().requires_grad_(True), txt.clone().requires_grad_(True)
+        li, lt = lr[0].clone().requires_grad_(True), lr[1].clone().requires_grad_(True)
+        perms = [torch.from_numpy(p) for p in g["perms"][it]]
+        grand, aux = dr.unrolled_match(fi, ft, ir, tr, li, lt, T("theta0_img"), T("theta0_txt"),
+                                       T("target_img"), T("target_txt"), perms)
+        gi, gt, gli, glt = dr.outer_grads(grand, ir, tr, li, lt)
+        assert abs(grand.item() - float(g[f"it{it}_grand"])) < 1e-5 * abs(float(g[f"it{it}_grand"]))
+        assert rel_err(gi, T(f"it{it}_g_image_syn")) < 1e-4
+        assert rel_err(gt, T(f"it{it}_g_text_syn")) < 1e-4
+        img, txt = opt[0].step(img, gi), opt[1].step(txt, gt)
+        lr = opt[2].step(lr, torch.stack([gli, glt]))
+        assert rel_err(img, T(f"it{it}_image_syn_after")) < 1e-4
+        assert rel_err(lr, T(f"it{it}_lr_after")) < 1e-5
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout only exists in the build container")
+def test_flat_module_matches_reference_reparam_module():
+    sys.path.insert(0, REF)
+    import reparam_module  # the reference's own file (torch-only)
+    torch.manual_seed(0)
+    a = dr.ProjectionHead(16, 24)
+    b = dr.ProjectionHead(16, 24)
+    b.load_state_dict(a.state_dict())
+    fm = dr.FlatModule(a)
+    rm = reparam_module.ReparamModule(b)
+    assert tuple(fm.numels) == rm._param_numels
+    assert [tuple(s) for s in rm._param_shapes] == fm.shapes
+    th = torch.randn(fm.param_numel)
+    x = torch.randn(5, 16)
+    assert torch.allclose(fm(x, flat_param=th), rm(x, flat_param=th), atol=1e-6)

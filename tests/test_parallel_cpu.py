@@ -1,0 +1,62 @@
+"""world_size-2 gloo test of the N>1 path's host logic: fused gradient buffer, all-reduce mean,
+expert assignment and rank-identical minibatch permutations / SGD state."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle.distill_ref import SGDMomentum
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multimodal_dataset_distillation_amd import parallel as par
+    torch.manual_seed(0)
+    image_syn, text_syn = torch.randn(6, 3, 8, 8), torch.randn(6, 5)
+    lr = torch.tensor([0.1, 0.1])
+    flat, views = par.fused_grad_buffer(image_syn, text_syn)
+    opt = SGDMomentum(0.01)
+    state = torch.cat([image_syn.flatten(), text_syn.flatten(), lr])
+    experts = []
+    for it in range(3):
+        e = par.expert_for_rank(it, rank, world, 5)
+        experts.append(e)
+        perms = par.shared_permutations(6, 4, 2, it)
+        # stand-in for engine.unrolled_match: a rank/expert-specific gradient written through the views
+        g = torch.Generator().manual_seed(1000 + e)
+        views["image_syn"].copy_(torch.randn(image_syn.shape, generator=g))
+        views["text_syn"].copy_(torch.randn(text_syn.shape, generator=g))
+        views["lr"].copy_(torch.randn(2, generator=g))
+        par.average_gradients_(flat)
+        state = opt.step(state, flat.clone())
+    out[rank] = dict(state=state, experts=experts, perms=perms, flat=flat.clone())
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_averaging_and_identical_updates():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    a, b = out[0], out[1]
+    assert torch.equal(a["state"], b["state"])          # identical synthetic set on every rank
+    assert torch.equal(a["perms"], b["perms"])
+    assert a["experts"] == [0, 2, 4] and b["experts"] == [1, 3, 0]
+    # last reduced buffer is the mean of the two ranks' expert gradients
+    def grad(e):
+        g = torch.Generator().manual_seed(1000 + e)
+        return torch.cat([torch.randn(6, 3, 8, 8, generator=g).flatten(),
+                          torch.randn(6, 5, generator=g).flatten(), torch.randn(2, generator=g)])
+    assert torch.allclose(a["flat"], 0.5 * (grad(4) + grad(0)), atol=1e-6)
