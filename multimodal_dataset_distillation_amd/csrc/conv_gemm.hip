@@ -65,7 +65,14 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
   const int wm = wave / WGN, wn = wave - wm * WGN;
 
   // block -> (m tile, group, n tile); n tile fastest so neighbours share the A panel in L2
-  int bid = blockIdx.x;
+  // XCD-aware remap (8 XCDs, private L2s, blocks dealt round-robin): give every XCD a CONTIGUOUS
+  // chunk of logical ids so the n-tiles / groups of one m-tile share the A panel in ONE L2 instead
+  // of re-fetching it through the fabric once per XCD.  Bijective for any grid size.
+  int bid;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  }
   const int nt = bid % p.ntiles; bid /= p.ntiles;
   const int grp = bid % G.groups;
   const int mt = bid / G.groups;

@@ -50,13 +50,23 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const WArgs p) {
   const ConvGeom& G = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wc = wave / WKP, wk = wave - wc * WKP;
-  int bid = blockIdx.x;
+  // XCD-aware remap of the linear block id (8 XCDs, private L2s, round-robin dispatch): all output
+  // tiles of ONE M-chunk get consecutive logical ids -> one XCD -> its dy / x rows are fetched
+  // through the fabric once instead of once per XCD.  Bijective for any grid size.
+  int bid, bsplit;
+  {
+    const int nwg = gridDim.x * gridDim.y, orig = blockIdx.x + blockIdx.y * gridDim.x;
+    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    bsplit = lin / gridDim.x;
+    bid = lin - bsplit * gridDim.x;
+  }
   const int kpt = bid % p.kptiles; bid /= p.kptiles;
   const int cot = bid % p.cotiles;
   const int grp = bid / p.cotiles;
   const int co0 = cot * BCO, kp0 = kpt * BKP;
   const int ktot = G.k * G.k * G.kc;
-  const int mbeg = blockIdx.y * p.mchunk;
+  const int mbeg = bsplit * p.mchunk;
   const int mend = min(p.M, mbeg + p.mchunk);
   const int niter1 = mend > mbeg ? (mend - mbeg + BKM - 1) / BKM : 0;
   const int niter = p.dy2 ? 2 * niter1 : niter1;

@@ -13,6 +13,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 #include <algorithm>
@@ -400,6 +401,11 @@ struct Eng : mdd_engine {
     HIP_CHECK_RET(hipMemsetAsync(wf_t, 0, packed_total * sizeof(AT), st));
     HIP_CHECK_RET(hipMemsetAsync(wt_t, 0, packed_total * sizeof(AT), st));
     HIP_CHECK_RET(hipStreamSynchronize(st));  // descs.data() is host memory
+    if (!side) {
+      const char* env = getenv("MDD_SIDE_STREAM");
+      use_side = !(env && env[0] == '0');
+      if (use_side) HIP_CHECK_RET(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    }
     return 0;
   }
 
@@ -416,6 +422,28 @@ struct Eng : mdd_engine {
     g.nc = L.cin_pad / L.groups; g.groups = L.groups; g.k = L.k; g.stride = L.stride; g.pad = L.pad;
     g.transposed = 1; return g;
   }
+
+  // ---- side stream: weight-gradient contractions only depend on (dy, x) of their own layer, so
+  // they run beside the data-gradient chain instead of in it (both are latency-bound on their own).
+  hipStream_t side = nullptr;
+  bool use_side = true;
+  std::vector<hipEvent_t> evs;
+  size_t evi = 0;
+  hipEvent_t next_event() {
+    if (evs.size() < 512) {
+      hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableTiming); evs.push_back(e); return e;
+    }
+    return evs[evi++ % evs.size()];
+  }
+  void fork(hipStream_t st) {  // side waits for everything enqueued on st so far
+    if (!use_side) return;
+    hipEvent_t e = next_event(); hipEventRecord(e, st); hipStreamWaitEvent(side, e, 0);
+  }
+  void join(hipStream_t st) {  // st waits for everything enqueued on side so far
+    if (!use_side) return;
+    hipEvent_t e = next_event(); hipEventRecord(e, side); hipStreamWaitEvent(st, e, 0);
+  }
+  hipStream_t wstream(hipStream_t st) const { return use_side ? side : st; }
 
   // ---- optional HIP-event timing of every contraction launch (bench.py roofline accounting)
   struct Prof { int kind; double flops, bytes; hipEvent_t a, b; ConvGeom g; int ns; };
@@ -499,8 +527,10 @@ struct Eng : mdd_engine {
   void conv_bwd_w(bool T, const ConvL& L, const AT* dy, const AT* dy_t, const AT* x, const AT* x_t,
                   float* dwf_, float* dwf_t_, float* gout, hipStream_t st) {
     ConvGeom g = gfwd(L);
-    if (!T) wgrad(L, g, dy, x, nullptr, nullptr, dwf_ + L.off_p, gout + L.off_b, st);
-    else wgrad(L, g, dy_t, x, x_t ? dy : nullptr, x_t, dwf_t_ + L.off_p, gout + L.off_b, st);
+    fork(st);
+    hipStream_t ws_ = wstream(st);
+    if (!T) wgrad(L, g, dy, x, nullptr, nullptr, dwf_ + L.off_p, gout + L.off_b, ws_);
+    else wgrad(L, g, dy_t, x, x_t ? dy : nullptr, x_t, dwf_t_ + L.off_p, gout + L.off_b, ws_);
   }
   // data gradient of conv L with fused epilogue
   void conv_bwd_d(bool T, const ConvL& L, const AT* dy, const AT* dy_t, ConvEpi e, hipStream_t st) {
@@ -613,14 +643,16 @@ struct Eng : mdd_engine {
                               T ? qa.C3 : nullptr, ga, N, hw, c, st);
       launch_small_pointwise(0, oa.zB, T ? qa.zB : nullptr, oa.gateB, T ? qa.gateB : nullptr,
                              pa.gate, T ? qa.gate : nullptr, N * c, st);
+      fork(st);
       launch_linear_wgrad(gout + B.se.off_w2, gout + B.se.off_b2, oa.zB, T ? qa.zB : nullptr, pa.h,
-                          T ? qa.h : nullptr, N, rd, c, st);
+                          T ? qa.h : nullptr, N, rd, c, wstream(st));
       launch_linear_dgrad(se_tmp, T ? se_tmp_t : nullptr, oa.zB, T ? qa.zB : nullptr,
                           th + B.se.off_w2, T ? th_t + B.se.off_w2 : nullptr, N, rd, c, st);
       launch_small_pointwise(1, oa.hB, T ? qa.hB : nullptr, se_tmp, T ? se_tmp_t : nullptr, pa.h,
                              T ? qa.h : nullptr, N * rd, st);
+      fork(st);
       launch_linear_wgrad(gout + B.se.off_w1, gout + B.se.off_b1, oa.hB, T ? qa.hB : nullptr, pa.p,
-                          T ? qa.p : nullptr, N, c, rd, st);
+                          T ? qa.p : nullptr, N, c, rd, wstream(st));
       launch_linear_dgrad(oa.pB, T ? qa.pB : nullptr, oa.hB, T ? qa.hB : nullptr, th + B.se.off_w1,
                           T ? th_t + B.se.off_w1 : nullptr, N, c, rd, st);
       launch_se_apply_bwd<AT>(oa.C3B, T ? qa.C3B : nullptr, xb, T ? xb_t : nullptr, pa.gate,
@@ -671,6 +703,7 @@ struct Eng : mdd_engine {
       conv_bwd_d(T, convs[stem[0]], O.CsB[0], Q.CsB[0], epi_lin(x0b, nullptr), st);
       launch_img_scatter_grad<AT>(dimage, x0b, idx, coef, mul, N, 3, S, S, 8, st);
     }
+    join(st);
     launch_ws_backward(d_descs, (int)descs.size(), total_rows, th, T ? th_t : nullptr, dw,
                        T ? dw_t : nullptr, gout, st);
     POST_LAUNCH("img_backward");
