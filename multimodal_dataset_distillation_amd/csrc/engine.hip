@@ -405,6 +405,7 @@ struct Eng : mdd_engine {
       const char* env = getenv("MDD_SIDE_STREAM");
       use_side = !(env && env[0] == '0');
       if (use_side) HIP_CHECK_RET(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+      if (use_side) HIP_CHECK_RET(hipStreamCreateWithFlags(&tside, hipStreamNonBlocking));
     }
     return 0;
   }
@@ -444,6 +445,12 @@ struct Eng : mdd_engine {
     hipEvent_t e = next_event(); hipEventRecord(e, side); hipStreamWaitEvent(st, e, 0);
   }
   hipStream_t wstream(hipStream_t st) const { return use_side ? side : st; }
+  hipStream_t tside = nullptr;   // text-projection stream
+  void fork_to(hipStream_t to, hipStream_t from) {
+    if (to == from) return;
+    hipEvent_t e = next_event(); hipEventRecord(e, from); hipStreamWaitEvent(to, e, 0);
+  }
+  void join_from(hipStream_t from, hipStream_t to) { fork_to(to, from); }
 
   // ---- optional HIP-event timing of every contraction launch (bench.py roofline accounting)
   struct Prof { int kind; double flops, bytes; hipEvent_t a, b; ConvGeom g; int ns; };
@@ -786,6 +793,7 @@ struct Eng : mdd_engine {
     const int Ks = a->syn_steps;
     const float* scale_dev = a->use_lr_as_scale ? a->lr_img : nullptr;
     const int64_t nfeat = (int64_t)N * feat;
+    hipStream_t ts = (use_side && tside) ? tside : st;
     int rc;
     std::vector<const float*> tI(Ks + 1), tT(Ks + 1);
     tI[0] = a->theta0_img; tT[0] = a->theta0_txt;
@@ -795,18 +803,24 @@ struct Eng : mdd_engine {
     for (int k = 0; k < Ks; ++k) {
       const int64_t* idx = a->perms ? a->perms + (int64_t)k * N : nullptr;
       const float* mask = a->drop_masks ? a->drop_masks + (int64_t)k * nfeat : nullptr;
+      // the text projection runs on its own stream beside the image encoder; they meet at the
+      // contrastive head
+      fork_to(ts, st);
+      if ((rc = txt_forward(false, k, tT[k], nullptr, a->text_syn, idx, mask, nullptr, ts))) return rc;
       if ((rc = img_forward(false, k, tI[k], nullptr, a->image_syn, idx, nullptr, st))) return rc;
-      if ((rc = txt_forward(false, k, tT[k], nullptr, a->text_syn, idx, mask, nullptr, st))) return rc;
+      join_from(ts, st);
       if ((rc = contrastive(false, sets[k].y, sets[k].ty, nullptr, nullptr, scale_dev,
                             a->logit_scale_const, a->losses + 3 + k, sets[k].yB, sets[k].tyB, sbar, st)))
         return rc;
+      fork_to(ts, st);
+      if ((rc = txt_backward(false, k, tT[k], nullptr, sets[k].tyB, nullptr, gT[k], nullptr, nullptr,
+                             nullptr, 0.f, true, ts))) return rc;
+      launch_axpy_out(thT[k + 1], tT[k], gT[k], a->lr_txt, -1.f, P_txt, ts);
       if ((rc = img_backward(false, k, tI[k], nullptr, sets[k].yB, nullptr, gI[k], nullptr, nullptr,
                              nullptr, 0.f, false, true, st))) return rc;
-      if ((rc = txt_backward(false, k, tT[k], nullptr, sets[k].tyB, nullptr, gT[k], nullptr, nullptr,
-                             nullptr, 0.f, true, st))) return rc;
       launch_axpy_out(thI[k + 1], tI[k], gI[k], a->lr_img, -1.f, P_img, st);
-      launch_axpy_out(thT[k + 1], tT[k], gT[k], a->lr_txt, -1.f, P_txt, st);
     }
+    join_from(ts, st);
     // ---- trajectory-matching loss (distill.py:584-598)
     launch_sqdist(tI[Ks], a->target_img, dsc + 0, P_img, st);
     launch_sqdist(a->theta0_img, a->target_img, dsc + 1, P_img, st);
@@ -820,22 +834,26 @@ struct Eng : mdd_engine {
     HIP_CHECK_RET(hipMemsetAsync(a->grad_text_syn, 0, (size_t)cfg.num_queries * Dt * 4, st));
     for (int k = Ks - 1; k >= 0; --k) {
       const int64_t* idx = a->perms ? a->perms + (int64_t)k * N : nullptr;
+      fork_to(ts, st);
+      launch_dot(gT[k], lamT, dsc + 5, -1.0, P_txt, ts);
+      launch_scale_out(nuT, lamT, a->lr_txt, 1.f, P_txt, ts);
+      if ((rc = txt_forward(true, k, tT[k], nuT, nullptr, nullptr, nullptr, fy_t, ts))) return rc;
       launch_dot(gI[k], lamI, dsc + 4, -1.0, P_img, st);   // d/d lr_img  -= <g_k, lambda>
-      launch_dot(gT[k], lamT, dsc + 5, -1.0, P_txt, st);
       launch_scale_out(nuI, lamI, a->lr_img, 1.f, P_img, st);  // direction v = lr * lambda
-      launch_scale_out(nuT, lamT, a->lr_txt, 1.f, P_txt, st);
       if ((rc = img_forward(true, k, tI[k], nuI, nullptr, nullptr, fx_t, st))) return rc;
-      if ((rc = txt_forward(true, k, tT[k], nuT, nullptr, nullptr, nullptr, fy_t, st))) return rc;
+      join_from(ts, st);
       if ((rc = contrastive(true, sets[k].y, sets[k].ty, fx_t, fy_t, scale_dev, a->logit_scale_const,
                             nullptr, xbar_t, ybar_t, sbar_t, st))) return rc;
+      fork_to(ts, st);
+      if ((rc = txt_backward(true, k, tT[k], nuT, nullptr, ybar_t, hT, a->grad_text_syn, idx, nullptr,
+                             -1.f, true, ts))) return rc;
+      launch_sub_inplace(lamT, hT, P_txt, ts);
       if ((rc = img_backward(true, k, tI[k], nuI, nullptr, xbar_t, hI, a->grad_image_syn, idx, nullptr,
                              -1.f, false, true, st))) return rc;
-      if ((rc = txt_backward(true, k, tT[k], nuT, nullptr, ybar_t, hT, a->grad_text_syn, idx, nullptr,
-                             -1.f, true, st))) return rc;
       if (a->use_lr_as_scale) launch_accum_f2d(dsc + 4, sbar_t, -1.0, st);
       launch_sub_inplace(lamI, hI, P_img, st);
-      launch_sub_inplace(lamT, hT, P_txt, st);
     }
+    join_from(ts, st);
     launch_d2f(a->grad_lr, dsc + 4, 1.f, 0, 2, st);
     POST_LAUNCH("unrolled_match");
     return 0;
