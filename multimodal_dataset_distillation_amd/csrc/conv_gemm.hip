@@ -42,6 +42,10 @@ template <> struct Mma<float> {
   }
 };
 
+DEVI uint4 mask4(uint4 v, bool keep) {
+  unsigned m = keep ? 0xffffffffu : 0u;
+  return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
+}
 DEVI int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 struct KArgs {
@@ -103,52 +107,68 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
   const int sh = G.stride >> 1;  // stride in {1,2}
 
   uint4 ra[RA], rb[RB];
+  // K cursor of this thread's chunk column: (tap, channel offset) advance by one K-step per tile
+  // with compare/subtract only -- no integer division and no divergent branches in the K loop.
+  // Loads are unconditional (invalid taps read offset 0 and are zeroed by a select).
+  int c_kidx, c_tap, c_kcq, c_ty, c_tx;
+  auto cursor_init = [&]() {
+    c_kidx = cj * CE;
+    c_tap = c_kidx / G.kc;
+    c_kcq = c_kidx - c_tap * G.kc;
+    c_ty = c_tap / G.k;
+    c_tx = c_tap - c_ty * G.k;
+  };
+  cursor_init();
+  bool okA[RA], okB[RB];   // validity of the staged chunks (zero-select deferred to the LDS store)
+  const size_t b_row0 = (size_t)(grp * G.nc + n0 + r0) * ktot;
   auto load_tile = [&](int kt) {
     const AT* A = (const AT*)(kt < nk1 ? p.A1 : p.A2);
     const AT* B = (const AT*)(kt < nk1 ? p.B1 : p.B2);
-    int kidx = (kt < nk1 ? kt : kt - nk1) * KE + cj * CE;
-    bool kok = kidx < ktot;
-    int tap = kidx / G.kc;
-    int kcq = kidx - tap * G.kc;
-    int ty = tap / G.k, tx = tap - ty * G.k;
+    if (kt == nk1) cursor_init();
+    const bool kok = c_kidx < ktot;
+    const int gk = grp * G.kc + c_kcq;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       int iy, ix;
       bool ok = kok;
       if (G.transposed) {
-        int ny = pby[i] - ty, nx = pbx[i] - tx;
+        int ny = pby[i] - c_ty, nx = pbx[i] - c_tx;
         ok = ok && ny >= 0 && nx >= 0 && ((ny | nx) & (G.stride - 1)) == 0;
         iy = ny >> sh; ix = nx >> sh;
         ok = ok && iy < G.ha && ix < G.wa;
       } else {
-        iy = pby[i] + ty; ix = pbx[i] + tx;
+        iy = pby[i] + c_ty; ix = pbx[i] + c_tx;
         ok = ok && (unsigned)iy < (unsigned)G.ha && (unsigned)ix < (unsigned)G.wa;
       }
-      if (ok) {
-        size_t off = ((size_t)(pbase[i] + iy * G.wa + ix)) * G.ca_tot + grp * G.kc + kcq;
-        ra[i] = *(const uint4*)(A + off);
-      } else {
-        ra[i] = make_uint4(0, 0, 0, 0);
-      }
+      size_t off = ok ? ((size_t)(pbase[i] + iy * G.wa + ix)) * G.ca_tot + gk : 0;
+      ra[i] = *(const uint4*)(A + off);
+      okA[i] = ok;
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      int n = n0 + r0 + 32 * i;
-      if (kok && n < G.nc) {
-        size_t off = ((size_t)(grp * G.nc + n)) * ktot + kidx;
-        rb[i] = *(const uint4*)(B + off);
-      } else {
-        rb[i] = make_uint4(0, 0, 0, 0);
-      }
+      bool ok = kok && (n0 + r0 + 32 * i) < G.nc;
+      size_t off = ok ? b_row0 + (size_t)(32 * i) * ktot + c_kidx : 0;
+      rb[i] = *(const uint4*)(B + off);
+      okB[i] = ok;
+    }
+    // advance the cursor by one K-step
+    c_kidx += KE;
+    c_kcq += KE;
+    while (c_kcq >= G.kc) {
+      c_kcq -= G.kc;
+      ++c_tap;
+      if (++c_tx == G.k) { c_tx = 0; ++c_ty; }
     }
   };
   auto store_tile = [&](int buf) {
     char* a = As + buf * BM * 128;
     char* b = Bs + buf * BN * 128;
 #pragma unroll
-    for (int i = 0; i < RA; ++i) *(uint4*)(a + lds_off(r0 + 32 * i, cj)) = ra[i];
+    for (int i = 0; i < RA; ++i)
+      *(uint4*)(a + lds_off(r0 + 32 * i, cj)) = mask4(ra[i], okA[i]);
 #pragma unroll
-    for (int i = 0; i < RB; ++i) *(uint4*)(b + lds_off(r0 + 32 * i, cj)) = rb[i];
+    for (int i = 0; i < RB; ++i)
+      *(uint4*)(b + lds_off(r0 + 32 * i, cj)) = mask4(rb[i], okB[i]);
   };
 
   f32x16 acc[TM][TN];
