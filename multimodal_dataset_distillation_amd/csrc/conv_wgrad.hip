@@ -28,6 +28,10 @@ struct WArgs {
 };
 
 // LDS chunk swizzle (bf16 path only): rows of ROWB bytes
+DEVI uint4 mask4(uint4 v, bool keep) {
+  unsigned m = keep ? 0xffffffffu : 0u;
+  return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
+}
 template <int ROWB> DEVI int wswz(int row) { return ROWB == 128 ? ((row >> 1) & 3) : (row & 7); }
 
 template <class AT, int BCO, int BKP, int BKM>
@@ -100,6 +104,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const WArgs p) {
   if (!pointwise) init_rows();
 
   uint4 rd[DSL], rx[XSL];
+  bool okD[DSL], okX[XSL], bias_now = false;   // zero-select deferred to the LDS store
   float bsum[CE];
 #pragma unroll
   for (int e = 0; e < CE; ++e) bsum[e] = 0.f;
@@ -114,17 +119,9 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const WArgs p) {
 #pragma unroll
     for (int i = 0; i < DSL; ++i) {
       int m = mb + drow + DSTEP * i;
-      if (m < mend && dco_ok) {
-        rd[i] = *(const uint4*)(DY + (size_t)m * G.co_tot + dy_col);
-        if (do_bias && !second) {
-          float f[CE];
-          Chunk<AT>::unpack(rd[i], f);
-#pragma unroll
-          for (int e = 0; e < CE; ++e) bsum[e] += f[e];
-        }
-      } else {
-        rd[i] = make_uint4(0, 0, 0, 0);
-      }
+      bool ok = m < mend && dco_ok;
+      okD[i] = ok;
+      rd[i] = *(const uint4*)(DY + (ok ? (size_t)m * G.co_tot + dy_col : 0));
     }
 #pragma unroll
     for (int i = 0; i < XSL; ++i) {
@@ -140,8 +137,10 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const WArgs p) {
         while (sox[i] >= G.wo) { sox[i] -= G.wo; ++soy[i]; }
         while (soy[i] >= G.ho) { soy[i] -= G.ho; ++sni[i]; }
       }
-      rx[i] = ok ? *(const uint4*)(X + pix * G.ca_tot + x_col) : make_uint4(0, 0, 0, 0);
+      okX[i] = ok;
+      rx[i] = *(const uint4*)(X + (ok ? pix * G.ca_tot + x_col : 0));
     }
+    bias_now = do_bias && !second;
   };
   auto store_tile = [&](int buf) {
     char* d = Ds + buf * DTILE;
@@ -150,13 +149,20 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const WArgs p) {
     for (int i = 0; i < DSL; ++i) {
       int r = drow + DSTEP * i;
       int c = BF ? (dcol ^ (wswz<DROWB>(r) << 1)) : dcol;
-      *(uint4*)(d + r * DROWB + c * 16) = rd[i];
+      uint4 v = mask4(rd[i], okD[i]);
+      *(uint4*)(d + r * DROWB + c * 16) = v;
+      if (bias_now) {
+        float f[CE];
+        Chunk<AT>::unpack(v, f);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) bsum[e] += f[e];
+      }
     }
 #pragma unroll
     for (int i = 0; i < XSL; ++i) {
       int r = xrow + XSTEP * i;
       int c = BF ? (xcol ^ (wswz<XROWB>(r) << 1)) : xcol;
-      *(uint4*)(x + r * XROWB + c * 16) = rx[i];
+      *(uint4*)(x + r * XROWB + c * 16) = mask4(rx[i], okX[i]);
     }
   };
 
