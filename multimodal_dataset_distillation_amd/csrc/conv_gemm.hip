@@ -55,7 +55,7 @@ struct KArgs {
   int M, mtiles, ntiles;
 };
 
-template <class AT, int WGM, int WGN, int TM, int TN>
+template <class AT, int WGM, int WGN, int TM, int TN, bool PW>
 __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   constexpr int RA = BM / 32, RB = BN / 32;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
       int t = m / G.wo;
       int oy = t % G.ho;
       int ni = t / G.ho;
-      pbase[i] = ni * G.ha * G.wa;
+      pbase[i] = PW ? m : ni * G.ha * G.wa;
       if (G.transposed) { pby[i] = oy + G.pad; pbx[i] = ox + G.pad; }
       else { pby[i] = oy * G.stride - G.pad; pbx[i] = ox * G.stride - G.pad; }
     } else {
@@ -127,6 +127,15 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
     if (kt == nk1) cursor_init();
     const bool kok = c_kidx < ktot;
     const int gk = grp * G.kc + c_kcq;
+    if constexpr (PW) {
+      // pointwise conv = plain GEMM: row m of A is pixel m, K = channels; one add per chunk
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        bool ok = kok && pby[i] >= 0;
+        okA[i] = ok;
+        ra[i] = *(const uint4*)(A + (ok ? (size_t)pbase[i] * G.ca_tot + c_kidx : 0));
+      }
+    } else
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       int iy, ix;
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
 }
 
 
-template <class AT, int WGM, int WGN, int TM, int TN>
+template <class AT, int WGM, int WGN, int TM, int TN, bool PW>
 void launch_cfg(const KArgs& a, hipStream_t st) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   KArgs k = a;
@@ -308,12 +317,12 @@ void launch_cfg(const KArgs& a, hipStream_t st) {
   if (shm_epi > shm) shm = shm_epi;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_conv_gemm<AT, WGM, WGN, TM, TN>,
+    (void)hipFuncSetAttribute((const void*)k_conv_gemm<AT, WGM, WGN, TM, TN, PW>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     attr_set = true;
   }
   int64_t blocks = (int64_t)k.mtiles * k.ntiles * a.g.groups;
-  k_conv_gemm<AT, WGM, WGN, TM, TN><<<(unsigned)blocks, 256, shm, st>>>(k);
+  k_conv_gemm<AT, WGM, WGN, TM, TN, PW><<<(unsigned)blocks, 256, shm, st>>>(k);
 }
 
 }  // namespace
@@ -327,9 +336,13 @@ void launch_conv_gemm(const ConvGeom& g, const AT* A1, const AT* B1, const AT* A
   a.M = g.nimg * g.ho * g.wo;
   a.mtiles = a.ntiles = 0;
   // tile selection by output-channel width per group
-  if (g.nc <= 32) launch_cfg<AT, 4, 1, 1, 1>(a, st);        // 128 x 32  (stem)
-  else if (g.nc <= 64) launch_cfg<AT, 4, 1, 2, 2>(a, st);   // 256 x 64  (group width 64)
-  else launch_cfg<AT, 2, 2, 2, 2>(a, st);                   // 128 x 128
+  const bool pw = g.k == 1 && g.stride == 1 && g.pad == 0 && g.groups == 1;  // pointwise: pure GEMM
+  if (g.nc <= 32) launch_cfg<AT, 4, 1, 1, 1, false>(a, st);        // 128 x 32  (stem)
+  else if (g.nc <= 64) {                                           // 256 x 64  (group width 64)
+    if (pw) launch_cfg<AT, 4, 1, 2, 2, true>(a, st); else launch_cfg<AT, 4, 1, 2, 2, false>(a, st);
+  } else {                                                         // 128 x 128
+    if (pw) launch_cfg<AT, 2, 2, 2, 2, true>(a, st); else launch_cfg<AT, 2, 2, 2, 2, false>(a, st);
+  }
 }
 template void launch_conv_gemm<float>(const ConvGeom&, const float*, const float*, const float*,
                                       const float*, const ConvEpi&, hipStream_t);
