@@ -16,6 +16,8 @@
 // of a ds_read_b128 hits 16 distinct 16-byte slots of the 256-byte bank row (conflict-free).
 // bf16: v_mfma_f32_32x32x16_bf16 ; f32 (parity mode): v_mfma_f32_32x32x2_f32 (exact fp32 FMA).
 // Fused epilogues (ConvEpi): bias, SiLU*beta, SiLU' / SiLU'' chain rule, residual adds.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace {
@@ -55,7 +57,7 @@ struct KArgs {
   int M, mtiles, ntiles;
 };
 
-template <class AT, int WGM, int WGN, int TM, int TN, bool PW>
+template <class AT, int WGM, int WGN, int TM, int TN, bool PW, bool PF2>
 __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   constexpr int RA = BM / 32, RB = BN / 32;
@@ -106,7 +108,8 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
   }
   const int sh = G.stride >> 1;  // stride in {1,2}
 
-  uint4 ra[RA], rb[RB];
+  struct Stage { uint4 ra[RA], rb[RB]; bool okA[RA], okB[RB]; };
+  Stage s0, s1;   // register stages: s1 only used by the 2-deep prefetch (PF2)
   // K cursor of this thread's chunk column: (tap, channel offset) advance by one K-step per tile
   // with compare/subtract only -- no integer division and no divergent branches in the K loop.
   // Loads are unconditional (invalid taps read offset 0 and are zeroed by a select).
@@ -119,9 +122,8 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
     c_tx = c_tap - c_ty * G.k;
   };
   cursor_init();
-  bool okA[RA], okB[RB];   // validity of the staged chunks (zero-select deferred to the LDS store)
   const size_t b_row0 = (size_t)(grp * G.nc + n0 + r0) * ktot;
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int kt, Stage& S) {
     const AT* A = (const AT*)(kt < nk1 ? p.A1 : p.A2);
     const AT* B = (const AT*)(kt < nk1 ? p.B1 : p.B2);
     if (kt == nk1) cursor_init();
@@ -132,8 +134,8 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
         bool ok = kok && pby[i] >= 0;
-        okA[i] = ok;
-        ra[i] = *(const uint4*)(A + (ok ? (size_t)pbase[i] * G.ca_tot + c_kidx : 0));
+        S.okA[i] = ok;
+        S.ra[i] = *(const uint4*)(A + (ok ? (size_t)pbase[i] * G.ca_tot + c_kidx : 0));
       }
     } else
 #pragma unroll
@@ -150,15 +152,15 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
         ok = ok && (unsigned)iy < (unsigned)G.ha && (unsigned)ix < (unsigned)G.wa;
       }
       size_t off = ok ? ((size_t)(pbase[i] + iy * G.wa + ix)) * G.ca_tot + gk : 0;
-      ra[i] = *(const uint4*)(A + off);
-      okA[i] = ok;
+      S.ra[i] = *(const uint4*)(A + off);
+      S.okA[i] = ok;
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       bool ok = kok && (n0 + r0 + 32 * i) < G.nc;
       size_t off = ok ? b_row0 + (size_t)(32 * i) * ktot + c_kidx : 0;
-      rb[i] = *(const uint4*)(B + off);
-      okB[i] = ok;
+      S.rb[i] = *(const uint4*)(B + off);
+      S.okB[i] = ok;
     }
     // advance the cursor by one K-step
     c_kidx += KE;
@@ -169,15 +171,15 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
       if (++c_tx == G.k) { c_tx = 0; ++c_ty; }
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const Stage& S) {
     char* a = As + buf * BM * 128;
     char* b = Bs + buf * BN * 128;
 #pragma unroll
     for (int i = 0; i < RA; ++i)
-      *(uint4*)(a + lds_off(r0 + 32 * i, cj)) = mask4(ra[i], okA[i]);
+      *(uint4*)(a + lds_off(r0 + 32 * i, cj)) = mask4(S.ra[i], S.okA[i]);
 #pragma unroll
     for (int i = 0; i < RB; ++i)
-      *(uint4*)(b + lds_off(r0 + 32 * i, cj)) = mask4(rb[i], okB[i]);
+      *(uint4*)(b + lds_off(r0 + 32 * i, cj)) = mask4(S.rb[i], S.okB[i]);
   };
 
   f32x16 acc[TM][TN];
@@ -188,14 +190,8 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-
   const int l31 = lane & 31, lh = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
+  auto compute = [&](int buf) {
     const char* a = As + buf * BM * 128;
     const char* b = Bs + buf * BN * 128;
 #pragma unroll
@@ -212,8 +208,36 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) Mma<AT>::step(af[i], bf[j], acc[i][j]);
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
+  };
+  if constexpr (!PF2) {
+    load_tile(0, s0);
+    store_tile(0, s0);
     __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) load_tile(kt + 1, s0);
+      compute(buf);
+      if (kt + 1 < nk) store_tile(buf ^ 1, s0);
+      __syncthreads();
+    }
+  } else {
+    // two tiles in flight: tile kt+2 is requested while tile kt is multiplied and tile kt+1 sits in
+    // registers waiting for its LDS slot -- every global load gets a full K-step to land
+    load_tile(0, s0);
+    if (nk > 1) load_tile(1, s1);
+    store_tile(0, s0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+      if (kt + 2 < nk) load_tile(kt + 2, s0);
+      compute(0);
+      if (kt + 1 < nk) store_tile(1, s1);
+      __syncthreads();
+      if (kt + 1 >= nk) break;
+      if (kt + 3 < nk) load_tile(kt + 3, s1);
+      compute(1);
+      if (kt + 2 < nk) store_tile(0, s0);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue.  The accumulators (C/D map of the 32x32 MFMA: col = lane&31,
@@ -306,7 +330,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
 }
 
 
-template <class AT, int WGM, int WGN, int TM, int TN, bool PW>
+template <class AT, int WGM, int WGN, int TM, int TN, bool PW, bool PF2>
 void launch_cfg(const KArgs& a, hipStream_t st) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   KArgs k = a;
@@ -317,12 +341,12 @@ void launch_cfg(const KArgs& a, hipStream_t st) {
   if (shm_epi > shm) shm = shm_epi;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_conv_gemm<AT, WGM, WGN, TM, TN, PW>,
+    (void)hipFuncSetAttribute((const void*)k_conv_gemm<AT, WGM, WGN, TM, TN, PW, PF2>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     attr_set = true;
   }
   int64_t blocks = (int64_t)k.mtiles * k.ntiles * a.g.groups;
-  k_conv_gemm<AT, WGM, WGN, TM, TN, PW><<<(unsigned)blocks, 256, shm, st>>>(k);
+  k_conv_gemm<AT, WGM, WGN, TM, TN, PW, PF2><<<(unsigned)blocks, 256, shm, st>>>(k);
 }
 
 }  // namespace
@@ -337,11 +361,11 @@ void launch_conv_gemm(const ConvGeom& g, const AT* A1, const AT* B1, const AT* A
   a.mtiles = a.ntiles = 0;
   // tile selection by output-channel width per group
   const bool pw = g.k == 1 && g.stride == 1 && g.pad == 0 && g.groups == 1;  // pointwise: pure GEMM
-  if (g.nc <= 32) launch_cfg<AT, 4, 1, 1, 1, false>(a, st);        // 128 x 32  (stem)
+  if (g.nc <= 32) launch_cfg<AT, 4, 1, 1, 1, false, false>(a, st);        // 128 x 32  (stem)
   else if (g.nc <= 64) {                                           // 256 x 64  (group width 64)
-    if (pw) launch_cfg<AT, 4, 1, 2, 2, true>(a, st); else launch_cfg<AT, 4, 1, 2, 2, false>(a, st);
+    if (pw) launch_cfg<AT, 4, 1, 2, 2, true, false>(a, st); else launch_cfg<AT, 4, 1, 2, 2, false, false>(a, st);
   } else {                                                         // 128 x 128
-    if (pw) launch_cfg<AT, 2, 2, 2, 2, true>(a, st); else launch_cfg<AT, 2, 2, 2, 2, false>(a, st);
+    if (pw) launch_cfg<AT, 2, 2, 2, 2, true, false>(a, st); else launch_cfg<AT, 2, 2, 2, 2, false, false>(a, st);
   }
 }
 template void launch_conv_gemm<float>(const ConvGeom&, const float*, const float*, const float*,
