@@ -16,6 +16,8 @@
 // The M range is split across blockIdx.y and combined with fp32 atomics (dW is zeroed by the
 // caller).  An optional second pair (dy2, x2) is accumulated too (tangent pass), and the bias
 // gradient (column sums of dy1) is taken from the staging registers of the k'-tile-0 blocks.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace {
@@ -298,7 +300,8 @@ void launch_cfg(WArgs a, hipStream_t st) {
   a.cotiles = (g.nc + BCO - 1) / BCO;
   a.kptiles = (ktot + BKP - 1) / BKP;
   int tiles = a.cotiles * a.kptiles * g.groups;
-  int splits = (1024 + tiles - 1) / tiles;
+  static const int target = [] { const char* e = getenv("MDD_WG_BLOCKS"); return e ? atoi(e) : 384; }();
+  int splits = (target + tiles - 1) / tiles;
   int maxsplits = (a.M + 4 * BKM - 1) / (4 * BKM);
   if (splits > maxsplits) splits = maxsplits;
   if (splits < 1) splits = 1;
