@@ -106,7 +106,9 @@ template <class S, class T> DEVI void stS(T* pv, T* pt, size_t i, S x) {
 }
 
 // ------------------------------------------------------------------ scalar math, float + Dual
-DEVI float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp): the full-precision division sequence costs ~10 VALU ops per element
+// and the conv epilogues (SiLU and its derivatives on every output element) are VALU-bound.
+DEVI float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 DEVI float rsqrt_(float x) { return rsqrtf(x); }
 DEVI Dual rsqrt_(Dual x) { float r = rsqrtf(x.v); return Dual(r, -0.5f * r * r * r * x.t); }
 DEVI float sqrt_(float x) { return sqrtf(x); }

@@ -22,11 +22,13 @@
 
 namespace {
 
+typedef unsigned __attribute__((ext_vector_type(4))) u32x4;   // first-class 16-byte register value
+
 template <class AT> struct Mma;
 template <> struct Mma<bf16> {
   static constexpr int KE = 64;  // K elements per 128-byte row
   static constexpr int CE = 8;   // elements per 16-byte chunk
-  static DEVI void step(const uint4& a, const uint4& b, f32x16& acc) {
+  static DEVI void step(const u32x4& a, const u32x4& b, f32x16& acc) {
     bf16x8 av = __builtin_bit_cast(bf16x8, a), bv = __builtin_bit_cast(bf16x8, b);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
   }
@@ -34,15 +36,17 @@ template <> struct Mma<bf16> {
 template <> struct Mma<float> {
   static constexpr int KE = 32;
   static constexpr int CE = 4;
-  static DEVI void step(const uint4& a, const uint4& b, f32x16& acc) {
+  static DEVI void step(const u32x4& a, const u32x4& b, f32x16& acc) {
     // lane-half h holds k = 4*(2q+h)+j, j=0..3 for BOTH operands: any k-permutation that is the
     // same for A and B leaves the sum unchanged.
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[0]), __uint_as_float(b[0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[1]), __uint_as_float(b[1]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[2]), __uint_as_float(b[2]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[3]), __uint_as_float(b[3]), acc, 0, 0, 0);
   }
 };
+
+__device__ __attribute__((aligned(16))) const unsigned g_zero_block[64] = {0};
 
 DEVI uint4 mask4(uint4 v, bool keep) {
   unsigned m = keep ? 0xffffffffu : 0u;
@@ -54,10 +58,10 @@ struct KArgs {
   const void* A1; const void* B1; const void* A2; const void* B2;
   ConvGeom g;
   ConvEpi ep;
-  int M, mtiles, ntiles, noremap;
+  int M, mtiles, ntiles, dbg;
 };
 
-template <class AT, int WGM, int WGN, int TM, int TN, bool PW, bool PF2>
+template <class AT, int WGM, int WGN, int TM, int TN, int MODE, bool KFULL>
 __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   constexpr int RA = BM / 32, RB = BN / 32;
@@ -78,7 +82,6 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
   {
     const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
     bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    if (p.noremap) bid = orig;
   }
   const int nt = bid % p.ntiles; bid /= p.ntiles;
   const int grp = bid % G.groups;
@@ -87,100 +90,145 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
 
   const int ktot = G.k * G.k * G.kc;
   const int nk1 = (ktot + KE - 1) / KE;
-  const int nk = p.A2 ? 2 * nk1 : nk1;
+  const int nk = (p.dbg & 1) ? 1 : (p.A2 ? 2 * nk1 : nk1);   // dbg bit0: single K-step (timing only)
 
-  // ---- per-thread staging geometry (fixed across the K loop)
+  // ---- per-thread staging geometry, hoisted out of the K loop (the loop is instruction-issue
+  // bound, not MFMA- or HBM-bound: every VALU op per load counts).
+  //   aoff[i] : byte offset of row i's source pixel at tap (0,0) (+ this thread's channel chunk for
+  //             pointwise convs); tapm[i]: bit t set <=> tap t of row i is inside the image.
+  //   Invalid taps / K tail / rows past M read a 16-byte zero block instead of being masked later.
+  constexpr int ESZ = (int)sizeof(AT);
   const int cj = tid & 7, r0 = tid >> 3;
-  int pbase[RA], pby[RA], pbx[RA];
+  const char* const Z = (const char*)g_zero_block;
+  int aoff[RA];
+  unsigned tapm[RA];
+  int s2y[MODE == 2 ? RA : 1], s2x[MODE == 2 ? RA : 1], s2b[MODE == 2 ? RA : 1];
+  // rows of this thread are m0 + r0 + 32*i: decode the first one with two divisions, advance the
+  // others incrementally (the prologue is paid by every block: thousands of blocks per launch)
+  int d_ox = 0, d_oy = 0, d_ni = 0;
+  if constexpr (MODE != 0) {
+    int m = m0 + r0;
+    d_ox = m % G.wo;
+    int t = m / G.wo;
+    d_oy = t % G.ho;
+    d_ni = t / G.ho;
+  }
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
     int m = m0 + r0 + 32 * i;
-    if (m < p.M) {
-      int ox = m % G.wo;
-      int t = m / G.wo;
-      int oy = t % G.ho;
-      int ni = t / G.ho;
-      pbase[i] = PW ? m : ni * G.ha * G.wa;
-      if (G.transposed) { pby[i] = oy + G.pad; pbx[i] = ox + G.pad; }
-      else { pby[i] = oy * G.stride - G.pad; pbx[i] = ox * G.stride - G.pad; }
+    if constexpr (MODE == 0) {
+      int mm = m < p.M ? m : p.M - 1;          // clamp: rows >= M are computed but never stored
+      aoff[i] = (mm * G.ca_tot + cj * CE) * ESZ;
+      tapm[i] = 1u;
     } else {
-      pbase[i] = 0; pby[i] = -(1 << 20); pbx[i] = -(1 << 20);
+      aoff[i] = 0; tapm[i] = 0u;
+      if constexpr (MODE == 2) { s2y[i] = -1; s2x[i] = -1; s2b[i] = 0; }
+      if (m < p.M) {
+        const int ox = d_ox, oy = d_oy, ni = d_ni;
+        int y0, x0;
+        if (G.transposed) { y0 = oy + G.pad; x0 = ox + G.pad; }
+        else { y0 = oy * G.stride - G.pad; x0 = ox * G.stride - G.pad; }
+        if constexpr (MODE == 2) {
+          s2y[i] = y0; s2x[i] = x0; s2b[i] = ni * G.ha * G.wa;
+          tapm[i] = 1u;   // validity evaluated per tap in the loop
+        } else {
+          aoff[i] = ((ni * G.ha + y0) * G.wa + x0) * G.ca_tot * ESZ;   // may be "negative": masked taps never use it
+          // valid taps form a rectangle [ylo,yhi] x [xlo,xhi]: build the bit mask from two ranges
+          int ylo, yhi, xlo, xhi;
+          if (G.transposed) { ylo = y0 - (G.ha - 1); yhi = y0; xlo = x0 - (G.wa - 1); xhi = x0; }
+          else { ylo = -y0; yhi = G.ha - 1 - y0; xlo = -x0; xhi = G.wa - 1 - x0; }
+          ylo = max(ylo, 0); xlo = max(xlo, 0); yhi = min(yhi, G.k - 1); xhi = min(xhi, G.k - 1);
+          unsigned xm = (xhi >= xlo) ? (((1u << (xhi - xlo + 1)) - 1u) << xlo) : 0u;
+          unsigned tm_ = 0u;
+          for (int ty = ylo; ty <= yhi; ++ty) tm_ |= xm << (ty * G.k);
+          tapm[i] = tm_;
+        }
+      }
+      // advance (ox, oy, ni) by 32 pixels
+      d_ox += 32;
+      while (d_ox >= G.wo) { d_ox -= G.wo; ++d_oy; }
+      while (d_oy >= G.ho) { d_oy -= G.ho; ++d_ni; }
     }
   }
-  const int sh = G.stride >> 1;  // stride in {1,2}
+  int boff[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    int n = n0 + r0 + 32 * i;
+    if (n >= G.nc) n = G.nc - 1;                 // clamp: columns >= nc are computed but never stored
+    boff[i] = ((grp * G.nc + n) * ktot + cj * CE) * ESZ;
+  }
+  // LDS byte addresses.  Rows 32 apart share the swizzle, so the i / j sub-tiles are reached with
+  // immediate offsets (i * 4096) from ONE register per q; the double buffer is toggled by XOR-ing
+  // one bit into these few registers per K-step (buffer strides are powers of two).
+  constexpr int ABUF = BM * 128, BBUF = BN * 128, BBASE = 2 * BM * 128;
+  const int l31 = lane & 31, lh = lane >> 5;
+  int rdA[4], rdB[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    rdA[q] = lds_off(wm * TM * 32 + l31, 2 * q + lh);
+    rdB[q] = BBASE + lds_off(wn * TN * 32 + l31, 2 * q + lh);
+  }
+  int wrA = lds_off(r0, cj), wrB = BBASE + lds_off(r0, cj);   // stage 0 goes to buffer 0
 
-  struct Stage { uint4 ra[RA], rb[RB]; bool okA[RA], okB[RB]; };
-  Stage s0, s1;   // register stages: s1 only used by the 2-deep prefetch (PF2)
-  // K cursor of this thread's chunk column: (tap, channel offset) advance by one K-step per tile
-  // with compare/subtract only -- no integer division and no divergent branches in the K loop.
-  // Loads are unconditional (invalid taps read offset 0 and are zeroed by a select).
-  int c_kidx, c_tap, c_kcq, c_ty, c_tx;
-  auto cursor_init = [&]() {
+  // K cursor of this thread's chunk column (generic path): advanced with compare/subtract only
+  int c_kidx = cj * CE, c_tap = 0, c_kcq = 0, c_ty = 0, c_tx = 0, c_tapoff = 0;
+  const int tap_row = G.wa * G.ca_tot * ESZ, tap_col = G.ca_tot * ESZ;
+  auto cursor_init = [&]() __attribute__((always_inline)) {
     c_kidx = cj * CE;
     c_tap = c_kidx / G.kc;
     c_kcq = c_kidx - c_tap * G.kc;
     c_ty = c_tap / G.k;
     c_tx = c_tap - c_ty * G.k;
+    c_tapoff = c_ty * tap_row + c_tx * tap_col;
   };
-  cursor_init();
-  const size_t b_row0 = (size_t)(grp * G.nc + n0 + r0) * ktot;
-  auto load_tile = [&](int kt, Stage& S) {
-    const AT* A = (const AT*)(kt < nk1 ? p.A1 : p.A2);
-    const AT* B = (const AT*)(kt < nk1 ? p.B1 : p.B2);
-    if (kt == nk1) cursor_init();
-    const bool kok = c_kidx < ktot;
-    const int gk = grp * G.kc + c_kcq;
-    if constexpr (PW) {
-      // pointwise conv = plain GEMM: row m of A is pixel m, K = channels; one add per chunk
+  if constexpr (MODE != 0) cursor_init();
+
+  struct Stage { u32x4 ra[RA], rb[RB]; };
+  Stage s0;
+  auto load_tile = [&](int kt, Stage& S) __attribute__((always_inline)) {
+    const bool second = kt >= nk1;
+    const char* A = (const char*)(second ? p.A2 : p.A1);
+    const char* B = (const char*)(second ? p.B2 : p.B1);
+    const int ks = second ? kt - nk1 : kt;          // K-step within the source
+    if constexpr (MODE == 0) {
+      const char* Ak = A + ks * 128;                // uniform base: zero VALU per load
+      const bool kok = KFULL || (ks * KE + cj * CE) < ktot;
+#pragma unroll
+      for (int i = 0; i < RA; ++i)
+        S.ra[i] = *(const u32x4*)(kok ? Ak + (unsigned)aoff[i] : Z);
+    } else {
+      if (kt == nk1) cursor_init();
+      const bool kok = c_kidx < ktot;
+      const int koff = (grp * G.kc + c_kcq) * ESZ + (G.transposed ? -c_tapoff : c_tapoff);
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
-        bool ok = kok && pby[i] >= 0;
-        S.okA[i] = ok;
-        S.ra[i] = *(const uint4*)(A + (ok ? (size_t)pbase[i] * G.ca_tot + c_kidx : 0));
+        if constexpr (MODE == 1) {
+          bool ok = kok && ((tapm[i] >> c_tap) & 1u);
+          S.ra[i] = *(const u32x4*)(ok ? A + (aoff[i] + koff) : Z);
+        } else {   // stride-2 data gradient: only taps of matching parity hit an input pixel
+          int ny = s2y[i] - c_ty, nx = s2x[i] - c_tx;
+          bool ok = kok && tapm[i] && ny >= 0 && nx >= 0 && ((ny | nx) & 1) == 0 &&
+                    (ny >> 1) < G.ha && (nx >> 1) < G.wa;
+          size_t off = ((size_t)(s2b[i] + (ny >> 1) * G.wa + (nx >> 1)) * G.ca_tot + grp * G.kc + c_kcq) * ESZ;
+          S.ra[i] = *(const u32x4*)(ok ? A + off : Z);
+        }
       }
-    } else
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-      int iy, ix;
-      bool ok = kok;
-      if (G.transposed) {
-        int ny = pby[i] - c_ty, nx = pbx[i] - c_tx;
-        ok = ok && ny >= 0 && nx >= 0 && ((ny | nx) & (G.stride - 1)) == 0;
-        iy = ny >> sh; ix = nx >> sh;
-        ok = ok && iy < G.ha && ix < G.wa;
-      } else {
-        iy = pby[i] + c_ty; ix = pbx[i] + c_tx;
-        ok = ok && (unsigned)iy < (unsigned)G.ha && (unsigned)ix < (unsigned)G.wa;
+      c_kidx += KE;
+      c_kcq += KE;
+      while (c_kcq >= G.kc) {
+        c_kcq -= G.kc;
+        ++c_tap;
+        if (++c_tx == G.k) { c_tx = 0; ++c_ty; }
+        c_tapoff = c_ty * tap_row + c_tx * tap_col;
       }
-      size_t off = ok ? ((size_t)(pbase[i] + iy * G.wa + ix)) * G.ca_tot + gk : 0;
-      S.ra[i] = *(const uint4*)(A + off);
-      S.okA[i] = ok;
     }
+    {
+      const char* Bk = B + ks * 128;
+      const bool kok = KFULL || (ks * KE + cj * CE) < ktot;
 #pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      bool ok = kok && (n0 + r0 + 32 * i) < G.nc;
-      size_t off = ok ? b_row0 + (size_t)(32 * i) * ktot + c_kidx : 0;
-      S.rb[i] = *(const uint4*)(B + off);
-      S.okB[i] = ok;
+      for (int i = 0; i < RB; ++i)
+        S.rb[i] = *(const u32x4*)(kok ? Bk + (unsigned)boff[i] : Z);
     }
-    // advance the cursor by one K-step
-    c_kidx += KE;
-    c_kcq += KE;
-    while (c_kcq >= G.kc) {
-      c_kcq -= G.kc;
-      ++c_tap;
-      if (++c_tx == G.k) { c_tx = 0; ++c_ty; }
-    }
-  };
-  auto store_tile = [&](int buf, const Stage& S) {
-    char* a = As + buf * BM * 128;
-    char* b = Bs + buf * BN * 128;
-#pragma unroll
-    for (int i = 0; i < RA; ++i)
-      *(uint4*)(a + lds_off(r0 + 32 * i, cj)) = mask4(S.ra[i], S.okA[i]);
-#pragma unroll
-    for (int i = 0; i < RB; ++i)
-      *(uint4*)(b + lds_off(r0 + 32 * i, cj)) = mask4(S.rb[i], S.okB[i]);
   };
 
   f32x16 acc[TM][TN];
@@ -191,54 +239,37 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int l31 = lane & 31, lh = lane >> 5;
-  auto compute = [&](int buf) {
-    const char* a = As + buf * BM * 128;
-    const char* b = Bs + buf * BN * 128;
+  auto store_tile = [&](const Stage& S) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) *(u32x4*)(smem + wrA + i * 4096) = S.ra[i];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) *(u32x4*)(smem + wrB + i * 4096) = S.rb[i];
+    wrA ^= ABUF; wrB ^= BBUF;
+  };
+  auto compute = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      uint4 af[TM], bf[TN];
+      u32x4 af[TM], bf[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        af[i] = *(const uint4*)(a + lds_off((wm * TM + i) * 32 + l31, 2 * q + lh));
+      for (int i = 0; i < TM; ++i) af[i] = *(const u32x4*)(smem + rdA[q] + i * 4096);
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bf[j] = *(const uint4*)(b + lds_off((wn * TN + j) * 32 + l31, 2 * q + lh));
+      for (int j = 0; j < TN; ++j) bf[j] = *(const u32x4*)(smem + rdB[q] + j * 4096);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) Mma<AT>::step(af[i], bf[j], acc[i][j]);
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { rdA[q] ^= ABUF; rdB[q] ^= BBUF; }
   };
-  if constexpr (!PF2) {
-    load_tile(0, s0);
-    store_tile(0, s0);
+  load_tile(0, s0);
+  store_tile(s0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_tile(kt + 1, s0);
+    compute();
+    if (kt + 1 < nk) store_tile(s0);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      const int buf = kt & 1;
-      if (kt + 1 < nk) load_tile(kt + 1, s0);
-      compute(buf);
-      if (kt + 1 < nk) store_tile(buf ^ 1, s0);
-      __syncthreads();
-    }
-  } else {
-    // two tiles in flight: tile kt+2 is requested while tile kt is multiplied and tile kt+1 sits in
-    // registers waiting for its LDS slot -- every global load gets a full K-step to land
-    load_tile(0, s0);
-    if (nk > 1) load_tile(1, s1);
-    store_tile(0, s0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-      if (kt + 2 < nk) load_tile(kt + 2, s0);
-      compute(0);
-      if (kt + 1 < nk) store_tile(1, s1);
-      __syncthreads();
-      if (kt + 1 >= nk) break;
-      if (kt + 3 < nk) load_tile(kt + 3, s1);
-      compute(1);
-      if (kt + 2 < nk) store_tile(0, s0);
-      __syncthreads();
-    }
   }
 
   // ---- epilogue.  The accumulators (C/D map of the 32x32 MFMA: col = lane&31,
@@ -248,6 +279,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
   constexpr int WROWS = TM * 32, WCOLS = TN * 32, PITCH = WCOLS + 4;
   constexpr int LPR = WCOLS / CE;      // lanes per output row
   constexpr int RPP = 64 / LPR;        // rows per pass
+  if (p.dbg & 4) return;   // dbg bit2: no epilogue at all (timing only)
   float* stage = (float*)smem + wave * (WROWS * PITCH);
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -301,7 +333,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
 #pragma unroll
         for (int e = 0; e < CE; ++e) v[e] += t0[e];
       }
-      if (out_raw) st(out_raw, idx, v);
+      if (out_raw && !(p.dbg & 2)) st(out_raw, idx, v);
       if (!out_act) continue;
       switch (E.mode) {
         case EPI_FWD:
@@ -325,13 +357,13 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
 #pragma unroll
         for (int e = 0; e < CE; ++e) o[e] += t0[e];
       }
-      st(out_act, idx, o);
+      if (!(p.dbg & 2)) st(out_act, idx, o);
     }
   }
 }
 
 
-template <class AT, int WGM, int WGN, int TM, int TN, bool PW, bool PF2>
+template <class AT, int WGM, int WGN, int TM, int TN, int MODE, bool KFULL>
 void launch_cfg(const KArgs& a, hipStream_t st) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   KArgs k = a;
@@ -342,12 +374,12 @@ void launch_cfg(const KArgs& a, hipStream_t st) {
   if (shm_epi > shm) shm = shm_epi;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_conv_gemm<AT, WGM, WGN, TM, TN, PW, PF2>,
+    (void)hipFuncSetAttribute((const void*)k_conv_gemm<AT, WGM, WGN, TM, TN, MODE, KFULL>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     attr_set = true;
   }
   int64_t blocks = (int64_t)k.mtiles * k.ntiles * a.g.groups;
-  k_conv_gemm<AT, WGM, WGN, TM, TN, PW, PF2><<<(unsigned)blocks, 256, shm, st>>>(k);
+  k_conv_gemm<AT, WGM, WGN, TM, TN, MODE, KFULL><<<(unsigned)blocks, 256, shm, st>>>(k);
 }
 
 }  // namespace
@@ -360,16 +392,26 @@ void launch_conv_gemm(const ConvGeom& g, const AT* A1, const AT* B1, const AT* A
   a.g = g; a.ep = ep;
   a.M = g.nimg * g.ho * g.wo;
   a.mtiles = a.ntiles = 0;
-  static const int noremap = [] { const char* e = getenv("MDD_NOREMAP"); return e && e[0] == '1' ? 1 : 0; }();
-  a.noremap = noremap;
+  static const int dbg = [] { const char* e = getenv("MDD_DBG"); return e ? atoi(e) : 0; }();
+  a.dbg = dbg;
   // tile selection by output-channel width per group
-  const bool pw = g.k == 1 && g.stride == 1 && g.pad == 0 && g.groups == 1;  // pointwise: pure GEMM
-  if (g.nc <= 32) launch_cfg<AT, 4, 1, 1, 1, false, false>(a, st);        // 128 x 32  (stem)
-  else if (g.nc <= 64) {                                           // 256 x 64  (group width 64)
-    if (pw) launch_cfg<AT, 4, 1, 2, 2, true, false>(a, st); else launch_cfg<AT, 4, 1, 2, 2, false, false>(a, st);
-  } else {                                                         // 128 x 128
-    if (pw) launch_cfg<AT, 2, 2, 2, 2, true, false>(a, st); else launch_cfg<AT, 2, 2, 2, 2, false, false>(a, st);
-  }
+  // MODE 0: pointwise (pure GEMM) ; 1: taps at linear offsets (any forward conv, stride-1 dgrad) ;
+  // 2: stride-2 data gradient.  KFULL: K is a whole number of 128-byte steps (no tail select).
+  const bool pw = g.k == 1 && g.stride == 1 && g.pad == 0 && g.groups == 1;
+  const int mode = pw ? 0 : ((g.transposed && g.stride == 2) ? 2 : 1);
+  const bool kfull = ((g.k * g.k * g.kc) % Mma<AT>::KE) == 0;
+#define MDD_DISPATCH(WGM, WGN, TM, TN)                                                        \
+  do {                                                                                        \
+    if (mode == 0) { if (kfull) launch_cfg<AT, WGM, WGN, TM, TN, 0, true>(a, st);            \
+                     else launch_cfg<AT, WGM, WGN, TM, TN, 0, false>(a, st); }               \
+    else if (mode == 1) { if (kfull) launch_cfg<AT, WGM, WGN, TM, TN, 1, true>(a, st);       \
+                          else launch_cfg<AT, WGM, WGN, TM, TN, 1, false>(a, st); }          \
+    else launch_cfg<AT, WGM, WGN, TM, TN, 2, false>(a, st);                                  \
+  } while (0)
+  if (g.nc <= 32) MDD_DISPATCH(4, 1, 1, 1);        // 128 x 32  (stem)
+  else if (g.nc <= 64) MDD_DISPATCH(4, 1, 2, 2);   // 256 x 64  (group width 64)
+  else MDD_DISPATCH(2, 2, 2, 2);                   // 128 x 128
+#undef MDD_DISPATCH
 }
 template void launch_conv_gemm<float>(const ConvGeom&, const float*, const float*, const float*,
                                       const float*, const ConvEpi&, hipStream_t);
