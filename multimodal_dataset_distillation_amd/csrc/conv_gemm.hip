@@ -86,9 +86,26 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
   const int nt = bid % p.ntiles; bid /= p.ntiles;
   const int grp = bid % G.groups;
   const int mt = bid / G.groups;
-  const int m0 = mt * BM, n0 = nt * BN;
+  // MODE 2 (stride-2 data gradient, even output dims): the output pixels are split into the four
+  // (oy&1, ox&1) parity classes.  Within a class only taps ty = ty0 + 2a, tx = tx0 + 2b hit an input
+  // pixel, at (oy/2 + cy - a, ox/2 + cx - b): a dense stride-1 problem on the half-resolution grid
+  // with 1, 2, 2 or 4 taps instead of 9 taps of which 3/4 multiply zeros.
+  int e_M = p.M, e_ho = G.ho, e_wo = G.wo, e_kh = G.k, e_kw = G.k;
+  int ty0 = 0, tx0 = 0, cy = 0, cx = 0, py = 0, px = 0, mt_ = mt;
+  if constexpr (MODE == 2) {
+    e_ho = G.ho >> 1; e_wo = G.wo >> 1; e_M = G.nimg * e_ho * e_wo;
+    const int mtc = (e_M + BM - 1) / BM;
+    const int cls = mt / mtc;
+    mt_ = mt - cls * mtc;
+    py = cls >> 1; px = cls & 1;
+    ty0 = (py + G.pad) & 1; tx0 = (px + G.pad) & 1;
+    e_kh = (G.k - ty0 + 1) >> 1; e_kw = (G.k - tx0 + 1) >> 1;
+    cy = (py + G.pad - ty0) >> 1; cx = (px + G.pad - tx0) >> 1;
+  }
+  const int m0 = mt_ * BM, n0 = nt * BN;
 
-  const int ktot = G.k * G.k * G.kc;
+  const int ktot_w = G.k * G.k * G.kc;          // K length of one packed weight row
+  const int ktot = e_kh * e_kw * G.kc;          // K extent this block reduces over
   const int nk1 = (ktot + KE - 1) / KE;
   const int nk = (p.dbg & 1) ? 1 : (p.A2 ? 2 * nk1 : nk1);   // dbg bit0: single K-step (timing only)
 
@@ -102,33 +119,34 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
   const char* const Z = (const char*)g_zero_block;
   int aoff[RA];
   unsigned tapm[RA];
-  int s2y[MODE == 2 ? RA : 1], s2x[MODE == 2 ? RA : 1], s2b[MODE == 2 ? RA : 1];
+  int s2y[MODE == 3 ? RA : 1], s2x[MODE == 3 ? RA : 1], s2b[MODE == 3 ? RA : 1];
   // rows of this thread are m0 + r0 + 32*i: decode the first one with two divisions, advance the
   // others incrementally (the prologue is paid by every block: thousands of blocks per launch)
   int d_ox = 0, d_oy = 0, d_ni = 0;
   if constexpr (MODE != 0) {
     int m = m0 + r0;
-    d_ox = m % G.wo;
-    int t = m / G.wo;
-    d_oy = t % G.ho;
-    d_ni = t / G.ho;
+    d_ox = m % e_wo;
+    int t = m / e_wo;
+    d_oy = t % e_ho;
+    d_ni = t / e_ho;
   }
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
     int m = m0 + r0 + 32 * i;
     if constexpr (MODE == 0) {
-      int mm = m < p.M ? m : p.M - 1;          // clamp: rows >= M are computed but never stored
+      int mm = m < e_M ? m : e_M - 1;          // clamp: rows >= M are computed but never stored
       aoff[i] = (mm * G.ca_tot + cj * CE) * ESZ;
       tapm[i] = 1u;
     } else {
       aoff[i] = 0; tapm[i] = 0u;
-      if constexpr (MODE == 2) { s2y[i] = -1; s2x[i] = -1; s2b[i] = 0; }
-      if (m < p.M) {
+      if constexpr (MODE == 3) { s2y[i] = -1; s2x[i] = -1; s2b[i] = 0; }
+      if (m < e_M) {
         const int ox = d_ox, oy = d_oy, ni = d_ni;
         int y0, x0;
-        if (G.transposed) { y0 = oy + G.pad; x0 = ox + G.pad; }
+        if constexpr (MODE == 2) { y0 = oy + cy; x0 = ox + cx; }
+        else if (G.transposed) { y0 = oy + G.pad; x0 = ox + G.pad; }
         else { y0 = oy * G.stride - G.pad; x0 = ox * G.stride - G.pad; }
-        if constexpr (MODE == 2) {
+        if constexpr (MODE == 3) {
           s2y[i] = y0; s2x[i] = x0; s2b[i] = ni * G.ha * G.wa;
           tapm[i] = 1u;   // validity evaluated per tap in the loop
         } else {
@@ -137,17 +155,17 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
           int ylo, yhi, xlo, xhi;
           if (G.transposed) { ylo = y0 - (G.ha - 1); yhi = y0; xlo = x0 - (G.wa - 1); xhi = x0; }
           else { ylo = -y0; yhi = G.ha - 1 - y0; xlo = -x0; xhi = G.wa - 1 - x0; }
-          ylo = max(ylo, 0); xlo = max(xlo, 0); yhi = min(yhi, G.k - 1); xhi = min(xhi, G.k - 1);
+          ylo = max(ylo, 0); xlo = max(xlo, 0); yhi = min(yhi, e_kh - 1); xhi = min(xhi, e_kw - 1);
           unsigned xm = (xhi >= xlo) ? (((1u << (xhi - xlo + 1)) - 1u) << xlo) : 0u;
           unsigned tm_ = 0u;
-          for (int ty = ylo; ty <= yhi; ++ty) tm_ |= xm << (ty * G.k);
+          for (int ty = ylo; ty <= yhi; ++ty) tm_ |= xm << (ty * e_kw);
           tapm[i] = tm_;
         }
       }
       // advance (ox, oy, ni) by 32 pixels
       d_ox += 32;
-      while (d_ox >= G.wo) { d_ox -= G.wo; ++d_oy; }
-      while (d_oy >= G.ho) { d_oy -= G.ho; ++d_ni; }
+      while (d_ox >= e_wo) { d_ox -= e_wo; ++d_oy; }
+      while (d_oy >= e_ho) { d_oy -= e_ho; ++d_ni; }
     }
   }
   int boff[RB];
@@ -155,7 +173,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
   for (int i = 0; i < RB; ++i) {
     int n = n0 + r0 + 32 * i;
     if (n >= G.nc) n = G.nc - 1;                 // clamp: columns >= nc are computed but never stored
-    boff[i] = ((grp * G.nc + n) * ktot + cj * CE) * ESZ;
+    boff[i] = ((grp * G.nc + n) * ktot_w + (MODE == 2 ? 0 : cj * CE)) * ESZ;
   }
   // LDS byte addresses.  Rows 32 apart share the swizzle, so the i / j sub-tiles are reached with
   // immediate offsets (i * 4096) from ONE register per q; the double buffer is toggled by XOR-ing
@@ -177,8 +195,8 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
     c_kidx = cj * CE;
     c_tap = c_kidx / G.kc;
     c_kcq = c_kidx - c_tap * G.kc;
-    c_ty = c_tap / G.k;
-    c_tx = c_tap - c_ty * G.k;
+    c_ty = c_tap / e_kw;
+    c_tx = c_tap - c_ty * e_kw;
     c_tapoff = c_ty * tap_row + c_tx * tap_col;
   };
   if constexpr (MODE != 0) cursor_init();
@@ -200,9 +218,12 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
       if (kt == nk1) cursor_init();
       const bool kok = c_kidx < ktot;
       const int koff = (grp * G.kc + c_kcq) * ESZ + (G.transposed ? -c_tapoff : c_tapoff);
+      // MODE 2: the class tap (a,b) is weight tap (ty0+2a, tx0+2b)
+      const int bt = MODE == 2 ? (((ty0 + 2 * c_ty) * G.k + tx0 + 2 * c_tx) * G.kc + c_kcq) * ESZ : 0;
+      const bool bok2 = kok;
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
-        if constexpr (MODE == 1) {
+        if constexpr (MODE == 1 || MODE == 2) {
           bool ok = kok && ((tapm[i] >> c_tap) & 1u);
           S.ra[i] = *(const u32x4*)(ok ? A + (aoff[i] + koff) : Z);
         } else {   // stride-2 data gradient: only taps of matching parity hit an input pixel
@@ -218,11 +239,16 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
       while (c_kcq >= G.kc) {
         c_kcq -= G.kc;
         ++c_tap;
-        if (++c_tx == G.k) { c_tx = 0; ++c_ty; }
+        if (++c_tx == e_kw) { c_tx = 0; ++c_ty; }
         c_tapoff = c_ty * tap_row + c_tx * tap_col;
       }
+      if constexpr (MODE == 2) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+          S.rb[i] = *(const u32x4*)(bok2 ? B + (boff[i] + bt) : Z);
+      }
     }
-    {
+    if constexpr (MODE != 2) {
       const char* Bk = B + ks * 128;
       const bool kok = KFULL || (ks * KE + cj * CE) < ktot;
 #pragma unroll
@@ -318,8 +344,13 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
 #pragma unroll 4
     for (int ps = 0; ps < WROWS / RPP; ++ps) {
       const int row = ps * RPP + lrow;
-      const int m = m0 + wm * WROWS + row;
-      if (m >= p.M) continue;
+      int m = m0 + wm * WROWS + row;
+      if (m >= e_M) continue;
+      if constexpr (MODE == 2) {   // class-local pixel -> full-resolution output pixel
+        int oxc = m % e_wo, t = m / e_wo;
+        int oyc = t % e_ho, ni = t / e_ho;
+        m = (ni * G.ho + 2 * oyc + py) * G.wo + 2 * oxc + px;
+      }
       const size_t idx = (size_t)m * G.co_tot + ch;
       float v[CE], t0[CE], t1[CE], t2[CE], o[CE];
 #pragma unroll
@@ -368,6 +399,7 @@ void launch_cfg(const KArgs& a, hipStream_t st) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   KArgs k = a;
   k.mtiles = (a.M + BM - 1) / BM;
+  if (MODE == 2) k.mtiles = 4 * ((a.g.nimg * (a.g.ho / 2) * (a.g.wo / 2) + BM - 1) / BM);
   k.ntiles = (a.g.nc + BN - 1) / BN;
   size_t shm = 2 * (BM + BN) * 128;
   size_t shm_epi = 4 * (size_t)(TM * 32) * (TN * 32 + 4) * sizeof(float);  // per-wave transpose
@@ -398,7 +430,8 @@ void launch_conv_gemm(const ConvGeom& g, const AT* A1, const AT* B1, const AT* A
   // MODE 0: pointwise (pure GEMM) ; 1: taps at linear offsets (any forward conv, stride-1 dgrad) ;
   // 2: stride-2 data gradient.  KFULL: K is a whole number of 128-byte steps (no tail select).
   const bool pw = g.k == 1 && g.stride == 1 && g.pad == 0 && g.groups == 1;
-  const int mode = pw ? 0 : ((g.transposed && g.stride == 2) ? 2 : 1);
+  const bool s2t = g.transposed && g.stride == 2;
+  const int mode = pw ? 0 : (s2t ? (((g.ho | g.wo) & 1) == 0 && g.k <= 3 ? 2 : 3) : 1);
   const bool kfull = ((g.k * g.k * g.kc) % Mma<AT>::KE) == 0;
 #define MDD_DISPATCH(WGM, WGN, TM, TN)                                                        \
   do {                                                                                        \
@@ -406,7 +439,8 @@ void launch_conv_gemm(const ConvGeom& g, const AT* A1, const AT* B1, const AT* A
                      else launch_cfg<AT, WGM, WGN, TM, TN, 0, false>(a, st); }               \
     else if (mode == 1) { if (kfull) launch_cfg<AT, WGM, WGN, TM, TN, 1, true>(a, st);       \
                           else launch_cfg<AT, WGM, WGN, TM, TN, 1, false>(a, st); }          \
-    else launch_cfg<AT, WGM, WGN, TM, TN, 2, false>(a, st);                                  \
+    else if (mode == 2) launch_cfg<AT, WGM, WGN, TM, TN, 2, false>(a, st);                   \
+    else launch_cfg<AT, WGM, WGN, TM, TN, 3, false>(a, st);                                  \
   } while (0)
   if (g.nc <= 32) MDD_DISPATCH(4, 1, 1, 1);        // 128 x 32  (stem)
   else if (g.nc <= 64) MDD_DISPATCH(4, 1, 2, 2);   // 256 x 64  (group width 64)
