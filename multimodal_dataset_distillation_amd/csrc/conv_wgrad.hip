@@ -16,6 +16,7 @@
 // The M range is split across blockIdx.y and combined with fp32 atomics (dW is zeroed by the
 // caller).  An optional second pair (dy2, x2) is accumulated too (tangent pass), and the bias
 // gradient (column sums of dy1) is taken from the staging registers of the k'-tile-0 blocks.
+#include <cstdint>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -26,7 +27,7 @@ struct WArgs {
   const void* dy1; const void* x1; const void* dy2; const void* x2;
   float* dW; float* dbias;
   ConvGeom g;
-  int M, cotiles, kptiles, mchunk;
+  int M, cotiles, kptiles, mchunk, dbg;
 };
 
 // LDS chunk swizzle (bf16 path only): rows of ROWB bytes
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const WArgs p) {
   const int mbeg = bsplit * p.mchunk;
   const int mend = min(p.M, mbeg + p.mchunk);
   const int niter1 = mend > mbeg ? (mend - mbeg + BKM - 1) / BKM : 0;
-  const int niter = p.dy2 ? 2 * niter1 : niter1;
+  const int niter = (p.dbg & 1) ? (niter1 > 0 ? 1 : 0) : (p.dy2 ? 2 * niter1 : niter1);   // dbg bit0: timing only
 
   // ---- staging geometry.  dy: chunk col dcol, rows drow + DSTEP*i ; x: xcol, rows xrow + XSTEP*i
   const int dcol = tid % DCH, drow = tid / DCH;
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const WArgs p) {
     __syncthreads();
   }
 
+  if (p.dbg & 2) return;   // dbg bit1: no write-out (timing only)
   // ---- write-out: fp32 atomics into dW[g][co][k']
   float* dWg = p.dW + (size_t)grp * G.nc * ktot;
   if constexpr (!BF) {
@@ -300,15 +302,32 @@ void launch_cfg(WArgs a, hipStream_t st) {
   a.cotiles = (g.nc + BCO - 1) / BCO;
   a.kptiles = (ktot + BKP - 1) / BKP;
   int tiles = a.cotiles * a.kptiles * g.groups;
-  static const int target = [] { const char* e = getenv("MDD_WG_BLOCKS"); return e ? atoi(e) : 384; }();
-  int splits = (target + tiles - 1) / tiles;
-  int maxsplits = (a.M + 4 * BKM - 1) / (4 * BKM);
-  if (splits > maxsplits) splits = maxsplits;
-  if (splits < 1) splits = 1;
+  // Split-M policy from a two-term cost model measured on MI355X (tools/bench_wgrad.py): a block's
+  // K-loop is a serial chain of ~1.4 us steps (latency-bound), and every split adds one fp32-atomic
+  // pass over the output tile (chip-wide ~1.3 TB/s).  T(S) = waves(S) * (steps(S) * 1.4 us + 5 us)
+  //                                                    + out_bytes * S / 1.3 TB/s + 0.05 us * S.
+  const int nsrc = a.dy2 ? 2 : 1;
+  const double out_mb = (double)g.groups * g.nc * ktot * 4.0 / 1e6;
+  const int slots = 256 * 3;   // resident blocks on the chip at ~3 blocks per CU
+  const double tstep = (g.k == 1 && g.stride == 1) ? 0.8 : 1.4;   // us per K-step (pointwise / gathered)
+  int maxsplits = (a.M + 2 * BKM - 1) / (2 * BKM);
+  if (maxsplits < 1) maxsplits = 1;
+  int splits = 1;
+  double best = 1e30;
+  for (int sp = 1; sp <= maxsplits; sp = sp < 16 ? sp + 1 : sp + sp / 8) {
+    int chunk = ((a.M + sp - 1) / sp + BKM - 1) / BKM * BKM;
+    double steps = (double)nsrc * chunk / BKM;
+    double waves = (double)((int64_t)tiles * sp + slots - 1) / slots;
+    if (waves < 1.0) waves = 1.0;
+    double t = waves * (steps * tstep + 5.0) + out_mb * sp / 1.3 + 0.05 * sp;   // + contention per split
+    if (t < best) { best = t; splits = sp; }
+  }
   int mchunk = (a.M + splits - 1) / splits;
   mchunk = ((mchunk + BKM - 1) / BKM) * BKM;
   splits = (a.M + mchunk - 1) / mchunk;
   a.mchunk = mchunk;
+  static const int dbg = [] { const char* e = getenv("MDD_DBG"); return e ? atoi(e) : 0; }();
+  a.dbg = dbg;
   dim3 grid(tiles, splits);
   k_conv_wgrad<AT, BCO, BKP, BKM><<<grid, 256, 0, st>>>(a);
 }
