@@ -196,10 +196,13 @@ def main():
                 (PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS) * 1e12)
 
     # ---- roofline of the dominant kernel: one extra, HIP-event-instrumented iteration (rank 0)
-    if rank == 0 and not args.no_roofline:
-        lib.mdd_engine_profile(eng.h, 1)
+    if not args.no_roofline:
+        # every rank runs the extra iteration (it contains the all-reduce); only rank 0 records
+        if rank == 0:
+            lib.mdd_engine_profile(eng.h, 1)
         one_step()
         torch.cuda.synchronize()
+    if rank == 0 and not args.no_roofline:
         kinds = []
         buf = (C.c_double * 4)()
         for k in range(4):

