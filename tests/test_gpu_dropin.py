@@ -137,9 +137,11 @@ def test_config1_golden_scalars(dtype, report):
 
 
 @pytest.mark.parametrize("engine", ["fused", "autograd"])
-def test_distill_cli_runs_and_both_engines_agree(engine, report, tmp_path):
+def test_distill_cli_runs(engine, report, tmp_path):
     """The stage-2 driver with the reference's flags (plus synthetic experts): a few outer iterations
-    on the miniature topology; fused and autograd engines must produce the same synthetic set."""
+    on the miniature topology with either engine; student text dropout is active as in the reference
+    (distill.py:446-447), so the two runs are not compared number for number here -- the
+    dropout-free agreement of the two engines is test_autograd_dropin_matches_golden_tiny."""
     from multimodal_dataset_distillation_amd import distill, networks as nw
     argv = ["--image_encoder", "nfnet_tiny", "--num_queries", "4", "--mini_batch_size", "4",
             "--syn_steps", "2", "--expert_epochs", "1", "--max_start_epoch", "2", "--Iteration", "2",
@@ -149,9 +151,6 @@ def test_distill_cli_runs_and_both_engines_agree(engine, report, tmp_path):
     args, unknown = distill.build_parser().parse_known_args(argv)
     assert unknown == ["--an_unknown_flag", "1"]          # tolerated like reference distill.py:680-682
     torch.manual_seed(0)
-    # dropout is active in the student text projection (reference distill.py:446-447); both engines
-    # draw their masks from torch's device RNG in different orders, so compare with dropout folded out
-    import multimodal_dataset_distillation_amd.networks as networks
     img, txt, lr = distill.main(args)
     assert torch.isfinite(img).all() and torch.isfinite(txt).all() and torch.isfinite(lr).all()
     assert os.path.exists(os.path.join(str(tmp_path), "distilled_roco.pt"))
