@@ -144,12 +144,13 @@ __global__ void k_avgpool2_bwd(AT* __restrict__ din, const AT* __restrict__ dout
 
 // ------------------------------------------------------------------ per-(n,c) reductions over h*w
 // block = 256 threads = 8 chunk columns x 32 hw lanes.  MODE 0: mean x ; 1: mean silu(x) ;
-// 2: ga * sum a*b
+// 2: d = ga * sum a*b, then the sigmoid backward of the SE gate: out = d*g*(1-g)
 template <class S, class AT, int MODE>
 __global__ void k_hw_reduce(float* __restrict__ out, float* __restrict__ out_t,
                             const AT* __restrict__ a, const AT* __restrict__ a_t,
-                            const AT* __restrict__ b, const AT* __restrict__ b_t, float mul, int hw,
-                            int c) {
+                            const AT* __restrict__ b, const AT* __restrict__ b_t,
+                            const float* __restrict__ gate, const float* __restrict__ gate_t,
+                            float mul, int hw, int c) {
   constexpr int CE = Chunk<AT>::N;
   int cch = c / CE;
   int colgroups = (cch + 7) / 8;
@@ -199,8 +200,12 @@ __global__ void k_hw_reduce(float* __restrict__ out, float* __restrict__ out_t,
       stn += sh[l][cs][CE + e];
     }
     int64_t oi = (int64_t)ni * c + (int64_t)ccol * CE + e;
-    if constexpr (IsDual<S>::v) out_t[oi] = stn * mul;
-    else out[oi] = sv * mul;
+    S r = mk<S>(sv * mul, stn * mul);
+    if constexpr (MODE == 2) {
+      S g = ldS<S>(gate, gate_t, oi);
+      r = r * g * (1.f - g);
+    }
+    stS<S>(out, out_t, oi, r);
   }
 }
 
@@ -285,19 +290,6 @@ __global__ void k_final_pool_bwd(AT* __restrict__ cfbar, AT* __restrict__ cfbar_
   }
 }
 
-template <class S>
-__global__ void k_small_pointwise(int mode, float* __restrict__ out, float* __restrict__ out_t,
-                                  const float* __restrict__ a, const float* __restrict__ a_t,
-                                  const float* __restrict__ b, const float* __restrict__ b_t, int n) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    S x = ldS<S>(a, a_t, i), y = ldS<S>(b, b_t, i);
-    S r;
-    if (mode == 0) r = x * y * (1.f - y);          // z-bar = gate-bar * gate * (1 - gate)
-    else r = val(y) > 0.f ? x : mk<S>(0.f, 0.f);   // h-bar = g * [h > 0]
-    stS<S>(out, out_t, i, r);
-  }
-}
-
 }  // namespace
 
 // ====================================================================== launchers
@@ -330,7 +322,7 @@ template <class AT>
 void launch_pool_mean(float* p, const AT* x, int n, int hw, int c, hipStream_t st) {
   int colgroups = (c / Chunk<AT>::N + 7) / 8;
   k_hw_reduce<float, AT, 0><<<n * colgroups, 256, 0, st>>>(p, nullptr, x, nullptr, nullptr,
-                                                           nullptr, 1.f / hw, hw, c);
+                                                           nullptr, nullptr, nullptr, 1.f / hw, hw, c);
 }
 template <class AT>
 void launch_se_apply(const AT* c3, const AT* c3_t, const float* gate, const float* gate_t,
@@ -346,16 +338,16 @@ void launch_se_apply(const AT* c3, const AT* c3_t, const float* gate, const floa
                                                         hw, c);
 }
 template <class AT>
-void launch_se_gate_grad(float* dgate, float* dgate_t, const AT* xbar, const AT* xbar_t,
-                         const AT* c3, const AT* c3_t, float ga, int n, int hw, int c,
-                         hipStream_t st) {
+void launch_se_gate_grad(float* zbar, float* zbar_t, const AT* xbar, const AT* xbar_t,
+                         const AT* c3, const AT* c3_t, const float* gate, const float* gate_t,
+                         float ga, int n, int hw, int c, hipStream_t st) {
   int colgroups = (c / Chunk<AT>::N + 7) / 8;
   if (xbar_t)
-    k_hw_reduce<Dual, AT, 2><<<n * colgroups, 256, 0, st>>>(dgate, dgate_t, xbar, xbar_t, c3, c3_t,
-                                                            ga, hw, c);
+    k_hw_reduce<Dual, AT, 2><<<n * colgroups, 256, 0, st>>>(zbar, zbar_t, xbar, xbar_t, c3, c3_t,
+                                                            gate, gate_t, ga, hw, c);
   else
-    k_hw_reduce<float, AT, 2><<<n * colgroups, 256, 0, st>>>(dgate, nullptr, xbar, nullptr, c3,
-                                                             nullptr, ga, hw, c);
+    k_hw_reduce<float, AT, 2><<<n * colgroups, 256, 0, st>>>(zbar, nullptr, xbar, nullptr, c3,
+                                                             nullptr, gate, nullptr, ga, hw, c);
 }
 template <class AT>
 void launch_se_apply_bwd(AT* c3bar, AT* c3bar_t, const AT* xbar, const AT* xbar_t,
@@ -376,10 +368,10 @@ void launch_final_pool(float* y, float* y_t, const AT* cf, const AT* cf_t, int n
   int colgroups = (c / Chunk<AT>::N + 7) / 8;
   if (cf_t)
     k_hw_reduce<Dual, AT, 1><<<n * colgroups, 256, 0, st>>>(y, y_t, cf, cf_t, nullptr, nullptr,
-                                                            1.f / hw, hw, c);
+                                                            nullptr, nullptr, 1.f / hw, hw, c);
   else
     k_hw_reduce<float, AT, 1><<<n * colgroups, 256, 0, st>>>(y, nullptr, cf, nullptr, nullptr,
-                                                             nullptr, 1.f / hw, hw, c);
+                                                             nullptr, nullptr, nullptr, 1.f / hw, hw, c);
 }
 template <class AT>
 void launch_final_pool_bwd(AT* cfbar, AT* cfbar_t, const float* ybar, const float* ybar_t,
@@ -392,15 +384,6 @@ void launch_final_pool_bwd(AT* cfbar, AT* cfbar_t, const float* ybar, const floa
     k_final_pool_bwd<float, AT><<<egrid(total), 256, 0, st>>>(cfbar, nullptr, ybar, nullptr, cf,
                                                               nullptr, total, hw, c);
 }
-void launch_small_pointwise(int mode, float* out, float* out_t, const float* a, const float* a_t,
-                            const float* b, const float* b_t, int n, hipStream_t st) {
-  int grid = (n + 255) / 256;
-  if (out_t)
-    k_small_pointwise<Dual><<<grid, 256, 0, st>>>(mode, out, out_t, a, a_t, b, b_t, n);
-  else
-    k_small_pointwise<float><<<grid, 256, 0, st>>>(mode, out, nullptr, a, nullptr, b, nullptr, n);
-}
-
 #define INST(AT)                                                                                   \
   template void launch_img_gather_nhwc<AT>(AT*, const float*, const int64_t*, int, int, int, int,  \
                                            int, hipStream_t);                                      \
@@ -413,7 +396,8 @@ void launch_small_pointwise(int mode, float* out, float* out_t, const float* a, 
                                     const AT*, AT*, AT*, AT*, AT*, float, float, int, int, int,    \
                                     hipStream_t);                                                  \
   template void launch_se_gate_grad<AT>(float*, float*, const AT*, const AT*, const AT*,           \
-                                        const AT*, float, int, int, int, hipStream_t);             \
+                                        const AT*, const float*, const float*, float, int, int,    \
+                                        int, hipStream_t);                                         \
   template void launch_se_apply_bwd<AT>(AT*, AT*, const AT*, const AT*, const float*,              \
                                         const float*, const float*, const float*, float, int, int, \
                                         int, hipStream_t);                                         \

@@ -155,7 +155,7 @@ struct Eng : mdd_engine {
     AT *P, *SC, *C1, *A1, *C2, *A2, *C2b, *A2b, *C3;
     float *p, *h, *gate;
     AT *C3B, *A2bB, *C2bB, *A2B, *C2B, *A1B, *C1B, *AinB;
-    float *gateB, *zB, *hB, *pB;
+    float *zB, *hB, *pB;
   };
   struct ActSet {
     AT* X0;
@@ -180,7 +180,9 @@ struct Eng : mdd_engine {
   int64_t o_descs; WsDesc* d_descs = nullptr;
   AT *wf = nullptr, *wt = nullptr, *wf_t = nullptr, *wt_t = nullptr;
   AT *dsS = nullptr, *dsF = nullptr;       // downsample dgrad scratch (pooled / full res)
-  float *se_tmp = nullptr, *se_tmp_t = nullptr, *ln_stats = nullptr;
+  float* ln_stats = nullptr;
+  char* lin_mem[3] = {nullptr, nullptr, nullptr};   // split-K scratch: main / side / text stream
+  LinScratch lin_main, lin_side, lin_txt;
   float* lossw = nullptr;
   // unrolled-match state
   std::vector<float*> thI, thT, gI, gT;    // theta_k (k=1..K), g_k
@@ -336,7 +338,7 @@ struct Eng : mdd_engine {
       plan(&a.A2B, eout * B.mid, (p + "A2B").c_str(), slot);   plan(&a.C2B, eout * B.mid, (p + "C2B").c_str(), slot);
       plan(&a.A1B, ein * B.mid, (p + "A1B").c_str(), slot);    plan(&a.C1B, ein * B.mid, (p + "C1B").c_str(), slot);
       plan(&a.AinB, ein * B.cin, (p + "AinB").c_str(), slot);
-      plan(&a.gateB, n * B.se.c, (p + "gateB").c_str(), slot); plan(&a.zB, n * B.se.c, (p + "zB").c_str(), slot);
+      plan(&a.zB, n * B.se.c, (p + "zB").c_str(), slot);
       plan(&a.hB, n * B.se.rd, (p + "hB").c_str(), slot);      plan(&a.pB, n * B.se.c, (p + "pB").c_str(), slot);
     }
     int64_t ef = n * xh[nb] * xh[nb] * feat;
@@ -355,16 +357,15 @@ struct Eng : mdd_engine {
     o_descs = arena.take((int64_t)descs.size() * sizeof(WsDesc));
     plan(&wf, packed_total, "wf", -2); plan(&wt, packed_total, "wt", -2);
     plan(&wf_t, packed_total, "wf_t", -2); plan(&wt_t, packed_total, "wt_t", -2);
-    int64_t dsmax = 0, dfmax = 0, semax = 0;
+    int64_t dsmax = 0, dfmax = 0;
     for (auto& B : blks) {
       if (B.ds >= 0) {
         dsmax = std::max(dsmax, (int64_t)N * B.hout * B.hout * B.cin);
         dfmax = std::max(dfmax, (int64_t)N * B.hin * B.hin * B.cin);
       }
-      semax = std::max(semax, (int64_t)N * std::max(B.se.rd, B.se.c));
     }
     plan(&dsS, dsmax, "dsS", -2); plan(&dsF, dfmax, "dsF", -2);
-    plan(&se_tmp, semax, nullptr, -2); plan(&se_tmp_t, semax, nullptr, -2);
+    for (int i = 0; i < 3; ++i) plan(&lin_mem[i], lin_scratch_bytes(), nullptr, -2);
     plan(&ln_stats, (int64_t)N * 4, nullptr, -2);
     plan(&lossw, loss_work_floats(N, feat), nullptr, -2);
     sets.resize(K);
@@ -400,6 +401,9 @@ struct Eng : mdd_engine {
     HIP_CHECK_RET(hipMemsetAsync(wt, 0, packed_total * sizeof(AT), st));
     HIP_CHECK_RET(hipMemsetAsync(wf_t, 0, packed_total * sizeof(AT), st));
     HIP_CHECK_RET(hipMemsetAsync(wt_t, 0, packed_total * sizeof(AT), st));
+    for (int i = 0; i < 3; ++i) HIP_CHECK_RET(hipMemsetAsync(lin_mem[i], 0, lin_scratch_bytes(), st));
+    lin_main = lin_scratch_carve(lin_mem[0]); lin_side = lin_scratch_carve(lin_mem[1]);
+    lin_txt = lin_scratch_carve(lin_mem[2]);
     HIP_CHECK_RET(hipStreamSynchronize(st));  // descs.data() is host memory
     if (!side) {
       const char* env = getenv("MDD_SIDE_STREAM");
@@ -445,6 +449,7 @@ struct Eng : mdd_engine {
     hipEvent_t e = next_event(); hipEventRecord(e, side); hipStreamWaitEvent(st, e, 0);
   }
   hipStream_t wstream(hipStream_t st) const { return use_side ? side : st; }
+  const LinScratch& wlin() const { return use_side ? lin_side : lin_main; }
   hipStream_t tside = nullptr;   // text-projection stream
   void fork_to(hipStream_t to, hipStream_t from) {
     if (to == from) return;
@@ -598,10 +603,10 @@ struct Eng : mdd_engine {
       launch_pool_mean<AT>(T ? qa.p : pa.p, T ? qa.C3 : pa.C3, N, hw, c, st);
       launch_linear_fwd(pa.h, T ? qa.h : nullptr, pa.p, T ? qa.p : nullptr, th + B.se.off_w1,
                         T ? th_t + B.se.off_w1 : nullptr, th + B.se.off_b1,
-                        T ? th_t + B.se.off_b1 : nullptr, N, c, rd, 1, st);
+                        T ? th_t + B.se.off_b1 : nullptr, N, c, rd, 1, lin_main, st);
       launch_linear_fwd(pa.gate, T ? qa.gate : nullptr, pa.h, T ? qa.h : nullptr, th + B.se.off_w2,
                         T ? th_t + B.se.off_w2 : nullptr, th + B.se.off_b2,
-                        T ? th_t + B.se.off_b2 : nullptr, N, rd, c, 2, st);
+                        T ? th_t + B.se.off_b2 : nullptr, N, rd, c, 2, lin_main, st);
       bool lastb = b == nb - 1;
       launch_se_apply<AT>(pa.C3, T ? qa.C3 : nullptr, pa.gate, T ? qa.gate : nullptr, sc,
                           T ? sc_t : nullptr, P.X[b + 1], T ? Q.X[b + 1] : nullptr,
@@ -646,22 +651,18 @@ struct Eng : mdd_engine {
       const AT *xb = O.XB[b + 1], *xb_t = Q.XB[b + 1];
       int hw = B.hout * B.hout, c = B.se.c, rd = B.se.rd;
       // squeeze-excite backward
-      launch_se_gate_grad<AT>(oa.gateB, T ? qa.gateB : nullptr, xb, T ? xb_t : nullptr, pa.C3,
-                              T ? qa.C3 : nullptr, ga, N, hw, c, st);
-      launch_small_pointwise(0, oa.zB, T ? qa.zB : nullptr, oa.gateB, T ? qa.gateB : nullptr,
-                             pa.gate, T ? qa.gate : nullptr, N * c, st);
+      launch_se_gate_grad<AT>(oa.zB, T ? qa.zB : nullptr, xb, T ? xb_t : nullptr, pa.C3,
+                              T ? qa.C3 : nullptr, pa.gate, T ? qa.gate : nullptr, ga, N, hw, c, st);
+      launch_linear_dgrad(oa.hB, T ? qa.hB : nullptr, oa.zB, T ? qa.zB : nullptr,
+                          th + B.se.off_w2, T ? th_t + B.se.off_w2 : nullptr, pa.h, N, rd, c,
+                          lin_main, st);
       fork(st);
       launch_linear_wgrad(gout + B.se.off_w2, gout + B.se.off_b2, oa.zB, T ? qa.zB : nullptr, pa.h,
-                          T ? qa.h : nullptr, N, rd, c, wstream(st));
-      launch_linear_dgrad(se_tmp, T ? se_tmp_t : nullptr, oa.zB, T ? qa.zB : nullptr,
-                          th + B.se.off_w2, T ? th_t + B.se.off_w2 : nullptr, N, rd, c, st);
-      launch_small_pointwise(1, oa.hB, T ? qa.hB : nullptr, se_tmp, T ? se_tmp_t : nullptr, pa.h,
-                             T ? qa.h : nullptr, N * rd, st);
-      fork(st);
+                          T ? qa.h : nullptr, N, rd, c, wlin(), wstream(st));
       launch_linear_wgrad(gout + B.se.off_w1, gout + B.se.off_b1, oa.hB, T ? qa.hB : nullptr, pa.p,
-                          T ? qa.p : nullptr, N, c, rd, wstream(st));
+                          T ? qa.p : nullptr, N, c, rd, wlin(), wstream(st));
       launch_linear_dgrad(oa.pB, T ? qa.pB : nullptr, oa.hB, T ? qa.hB : nullptr, th + B.se.off_w1,
-                          T ? th_t + B.se.off_w1 : nullptr, N, c, rd, st);
+                          T ? th_t + B.se.off_w1 : nullptr, nullptr, N, c, rd, lin_main, st);
       launch_se_apply_bwd<AT>(oa.C3B, T ? qa.C3B : nullptr, xb, T ? xb_t : nullptr, pa.gate,
                               T ? qa.gate : nullptr, oa.pB, T ? qa.pB : nullptr, ga, N, hw, c, st);
       // residual branch
@@ -726,10 +727,10 @@ struct Eng : mdd_engine {
     if (!T) launch_gather_rows(P.tx, text, idx, N, Dt, st);
     auto tt = [&](int64_t o) { return T ? th_t + o : nullptr; };
     launch_linear_fwd(P.tp, T ? Q.tp : nullptr, P.tx, nullptr, th + t_pw, tt(t_pw), th + t_pb,
-                      tt(t_pb), N, Dt, feat, 0, st);
+                      tt(t_pb), N, Dt, feat, 0, lin_txt, st);
     launch_gelu(P.tg, T ? Q.tg : nullptr, P.tp, T ? Q.tp : nullptr, (int64_t)N * feat, st);
     launch_linear_fwd(P.tf, T ? Q.tf : nullptr, P.tg, T ? Q.tg : nullptr, th + t_fw, tt(t_fw),
-                      th + t_fb, tt(t_fb), N, feat, feat, 0, st);
+                      th + t_fb, tt(t_fb), N, feat, feat, 0, lin_txt, st);
     // the dropout mask of this slot is kept for the backward / tangent passes
     if (!T) slot_mask_[slot] = mask;
     launch_ln_fwd(P.ty, T ? feat_out : nullptr, P.tr, T ? Q.tr : nullptr, P.tf, T ? Q.tf : nullptr,
@@ -756,17 +757,17 @@ struct Eng : mdd_engine {
                   ln_stats, O.tyB, T ? ybar_t_in : nullptr, P.tr, T ? Q.tr : nullptr,
                   slot_mask_[slot], th + t_lw, tt(t_lw), N, feat, 1e-5f, st);
     launch_linear_wgrad(gout + t_fw, gout + t_fb, O.tfB, T ? Q.tfB : nullptr, P.tg,
-                        T ? Q.tg : nullptr, N, feat, feat, st);
+                        T ? Q.tg : nullptr, N, feat, feat, lin_txt, st);
     launch_linear_dgrad(O.tgB, T ? Q.tgB : nullptr, O.tfB, T ? Q.tfB : nullptr, th + t_fw, tt(t_fw),
-                        N, feat, feat, st);
+                        nullptr, N, feat, feat, lin_txt, st);
     launch_gelu_bwd(O.tpB, T ? Q.tpB : nullptr, O.trB, T ? Q.trB : nullptr, O.tgB,
                     T ? Q.tgB : nullptr, P.tp, T ? Q.tp : nullptr, (int64_t)N * feat, st);
     launch_linear_wgrad(gout + t_pw, gout + t_pb, O.tpB, T ? Q.tpB : nullptr, P.tx, nullptr, N, Dt,
-                        feat, st);
+                        feat, lin_txt, st);
     if (dtext) {
       float* xb = T ? Q.txB : O.txB;
       launch_linear_dgrad(O.txB, T ? Q.txB : nullptr, O.tpB, T ? Q.tpB : nullptr, th + t_pw,
-                          tt(t_pw), N, Dt, feat, st);
+                          tt(t_pw), nullptr, N, Dt, feat, lin_txt, st);
       launch_scatter_rows_axpy(dtext, xb, idx, coef, mul, N, Dt, st);
     }
     POST_LAUNCH("txt_backward");

@@ -109,11 +109,11 @@ template <class AT>
 void launch_se_apply(const AT* c3, const AT* c3_t, const float* gate, const float* gate_t,
                      const AT* sc, const AT* sc_t, AT* xo, AT* xo_t, AT* ao, AT* ao_t, float ga,
                      float beta, int n, int hw, int c, hipStream_t st);
-// dgate[n,c] = ga * sum_hw xbar*c3
+// zbar[n,c] = dgate*gate*(1-gate) with dgate[n,c] = ga * sum_hw xbar*c3  (sigmoid backward fused)
 template <class AT>
-void launch_se_gate_grad(float* dgate, float* dgate_t, const AT* xbar, const AT* xbar_t,
-                         const AT* c3, const AT* c3_t, float ga, int n, int hw, int c,
-                         hipStream_t st);
+void launch_se_gate_grad(float* zbar, float* zbar_t, const AT* xbar, const AT* xbar_t,
+                         const AT* c3, const AT* c3_t, const float* gate, const float* gate_t,
+                         float ga, int n, int hw, int c, hipStream_t st);
 // c3bar = xbar*gate*ga + pbar/hw
 template <class AT>
 void launch_se_apply_bwd(AT* c3bar, AT* c3bar_t, const AT* xbar, const AT* xbar_t,
@@ -127,21 +127,31 @@ void launch_final_pool(float* y, float* y_t, const AT* cf, const AT* cf_t, int n
 template <class AT>
 void launch_final_pool_bwd(AT* cfbar, AT* cfbar_t, const float* ybar, const float* ybar_t,
                            const AT* cf, const AT* cf_t, int n, int hw, int c, hipStream_t st);
-// small fp32 pointwise on [n] arrays: mode 0: z = dgate*gate*(1-gate) ; 1: h = g*[h>0]
-void launch_small_pointwise(int mode, float* out, float* out_t, const float* a, const float* a_t,
-                            const float* b, const float* b_t, int n, hipStream_t st);
 
 // ---------------------------------------------------------------- linear.hip (fp32, small M)
+// Split-K scratch of the small-M SGEMM: per-tile accumulators, bias-gradient row sums and arrival
+// counters (zeroed once at bind; every launch leaves them zero).  One per stream that runs linears.
+constexpr int64_t LIN_PART_FLOATS = 256 * 4096, LIN_PART_RS_FLOATS = 256 * 64;
+constexpr int LIN_CTR_N = 256;
+struct LinScratch {
+  float* part = nullptr; float* part_rs = nullptr; unsigned* ctr = nullptr;
+  int64_t part_floats = 0, part_rs_floats = 0; int ctr_n = 0;
+};
+int64_t lin_scratch_bytes();
+LinScratch lin_scratch_carve(void* base);
 // act: 0 none, 1 relu, 2 sigmoid.  Tangent inputs may be null individually (treated as 0).
+// Tangent forward reads the stashed post-activation primal from y and writes y_t only.
 void launch_linear_fwd(float* y, float* y_t, const float* x, const float* x_t, const float* W,
                        const float* W_t, const float* b, const float* b_t, int n, int k, int j,
-                       int act, hipStream_t st);
-// dx[n,k] = sum_j dy[n,j] W[j,k]
+                       int act, const LinScratch& ws, hipStream_t st);
+// dx[n,k] = sum_j dy[n,j] W[j,k], times [relu_of[n,k] > 0] when relu_of is given
 void launch_linear_dgrad(float* dx, float* dx_t, const float* dy, const float* dy_t,
-                         const float* W, const float* W_t, int n, int k, int j, hipStream_t st);
+                         const float* W, const float* W_t, const float* relu_of, int n, int k,
+                         int j, const LinScratch& ws, hipStream_t st);
 // dW[j,k] = sum_n dy[n,j] x[n,k] ; db[j] = sum_n dy[n,j]   (tangent pass writes tangents only)
 void launch_linear_wgrad(float* dW, float* db, const float* dy, const float* dy_t, const float* x,
-                         const float* x_t, int n, int k, int j, hipStream_t st);
+                         const float* x_t, int n, int k, int j, const LinScratch& ws,
+                         hipStream_t st);
 
 // ---------------------------------------------------------------- head.hip (fp32)
 void launch_gather_rows(float* out, const float* in, const int64_t* idx, int n, int d,

@@ -6,8 +6,16 @@
 //   forward  y[n,j]  = sum_k x[n,k]  W[j,k]      A = x  (k contiguous), B = W (k contiguous)
 //   dgrad    dx[n,k] = sum_j dy[n,j] W[j,k]      A = dy (j contiguous), B = W (n' contiguous)
 //   wgrad    dW[j,k] = sum_n dy[n,j] x[n,k]      A = dy (m contiguous), B = x (n' contiguous)
-// 64x64 output tile, 16-deep K step, 4x4 register micro-tile per thread, K split over blockIdx.z
-// with fp32 atomics when the tile count alone cannot fill 256 CUs (M is tiny).
+// 64x64 output tile, 16-deep K step, 4x4 register micro-tile per thread, 16-byte global loads along
+// whichever operand dimension is contiguous, next K slab prefetched into registers while the current
+// one is multiplied out of (double-buffered) LDS.
+//
+// M is tiny, so the tile count alone cannot fill 256 CUs: K is split over blockIdx.z.  Partial tiles
+// are added (fp32 atomics) into a per-stream scratch accumulator; the LAST block to arrive at a tile
+// (device-scope counter, self-resetting) swaps the sums out and applies the epilogue -- bias +
+// activation, the tangent of that, the ReLU mask of the SE backward, the bias-gradient row sums --
+// so a layer is ONE launch (no zero-fill + separate pointwise kernels).
+//
 // Tangent pass (forward-over-reverse): C_t = A_t*B + A*B_t in the same loop; either tangent
 // operand may be absent (= 0).
 #include <algorithm>
@@ -16,7 +24,9 @@
 
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 16, LDP = 68;  // LDS row pitch (floats): 16B-aligned, 2-way max on writes
+constexpr int BM = 64, BN = 64, BK = 16, LDP = 68;  // LDS row pitch (floats): 16B-aligned rows
+
+enum { EP_PLAIN = 0, EP_BIAS_ACT = 1, EP_BIAS_ACT_T = 2, EP_RELU_MASK = 3 };
 
 struct GArgs {
   const float *A, *A_t, *B, *B_t;
@@ -24,14 +34,22 @@ struct GArgs {
   int M, N, K;
   int64_t sAm, sAk, sBk, sBn;   // element strides
   int ksplit_len;       // K range per blockIdx.z (multiple of BK)
-  int atomic;           // 1: atomicAdd into zeroed C, 0: plain store
+  int splits;
+  int vecA, vecB, vecC; // 16-byte access legal for the operand (alignment + extents)
+  int epi, act;
+  const float* bias;    // EP_BIAS_ACT: b ; EP_BIAS_ACT_T: b_t (may be null)
+  const float* aux;     // EP_BIAS_ACT_T: stashed post-activation y ; EP_RELU_MASK: h
+  float* rowsum;        // optional: rowsum[m] = sum_k (MODE ? A_t : A)[m,k]   (bias gradient)
+  float* part; float* part_rs; unsigned* ctr;
 };
 
 // MODE 0: C = A*B ; MODE 1: C = A_t*B + A*B_t (null tangent = 0)
 template <int MODE>
-__global__ __launch_bounds__(256) void k_sgemm_small(const GArgs p) {
-  __shared__ __attribute__((aligned(16))) float As[BK][LDP], Bs[BK][LDP];
-  __shared__ __attribute__((aligned(16))) float Ats[MODE ? BK : 1][LDP], Bts[MODE ? BK : 1][LDP];
+__global__ __launch_bounds__(256, 4) void k_sgemm_small(const GArgs p) {
+  __shared__ __attribute__((aligned(16))) float As[2][BK][LDP], Bs[2][BK][LDP];
+  __shared__ __attribute__((aligned(16))) float Ats[MODE ? 2 : 1][MODE ? BK : 1][LDP],
+      Bts[MODE ? 2 : 1][MODE ? BK : 1][LDP];
+  __shared__ int s_last;
   const int tid = threadIdx.x;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int kbeg = blockIdx.z * p.ksplit_len;
@@ -42,157 +60,264 @@ __global__ __launch_bounds__(256) void k_sgemm_small(const GArgs p) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-  const bool a_kfast = p.sAk == 1;   // pick the loader mapping that coalesces along the unit stride
+  float rs[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool a_kfast = p.sAk == 1;   // which operand dimension is the unit stride
   const bool b_kfast = p.sBk == 1;
   const bool hasAt = MODE && p.A_t != nullptr, hasBt = MODE && p.B_t != nullptr;
+  const bool do_rs = p.rowsum != nullptr && blockIdx.x == 0;
 
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+  float ra[4], rb[4], rat[4], rbt[4];
+  auto load_op = [&](const float* P, const float* Pt, bool hasT, bool vec, bool kfast, int r0,
+                     int rmax, int64_t sr, int64_t sk, int k0, float* r, float* rt) {
+    if (vec) {
+      // one float4 per thread along the contiguous dimension
+      int row = kfast ? (tid >> 2) : ((tid & 15) * 4);
+      int kk = kfast ? ((tid & 3) * 4) : (tid >> 4);
+      bool ok = (r0 + row) < rmax && (k0 + kk) < kend;
+      int64_t off = (int64_t)(r0 + row) * sr + (int64_t)(k0 + kk) * sk;
+      float4 v = ok ? *(const float4*)(P + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+      r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+      if (MODE) {
+        float4 t = (ok && hasT) ? *(const float4*)(Pt + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rt[0] = t.x; rt[1] = t.y; rt[2] = t.z; rt[3] = t.w;
+      }
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int e = tid + 256 * i;
-      int kk = a_kfast ? (e & (BK - 1)) : (e >> 6);
-      int mm = a_kfast ? (e >> 4) : (e & 63);
-      bool ok = (m0 + mm) < p.M && (k0 + kk) < kend;
-      int64_t off = (int64_t)(m0 + mm) * p.sAm + (int64_t)(k0 + kk) * p.sAk;
-      As[kk][mm] = ok ? p.A[off] : 0.f;
-      if (MODE) Ats[kk][mm] = (ok && hasAt) ? p.A_t[off] : 0.f;
-      int kb = b_kfast ? (e & (BK - 1)) : (e >> 6);
-      int nn = b_kfast ? (e >> 4) : (e & 63);
-      bool okb = (n0 + nn) < p.N && (k0 + kb) < kend;
-      int64_t offb = (int64_t)(k0 + kb) * p.sBk + (int64_t)(n0 + nn) * p.sBn;
-      Bs[kb][nn] = okb ? p.B[offb] : 0.f;
-      if (MODE) Bts[kb][nn] = (okb && hasBt) ? p.B_t[offb] : 0.f;
+      for (int i = 0; i < 4; ++i) {
+        int e = tid + 256 * i;
+        int kk = kfast ? (e & (BK - 1)) : (e >> 6);
+        int row = kfast ? (e >> 4) : (e & 63);
+        bool ok = (r0 + row) < rmax && (k0 + kk) < kend;
+        int64_t off = (int64_t)(r0 + row) * sr + (int64_t)(k0 + kk) * sk;
+        r[i] = ok ? P[off] : 0.f;
+        if (MODE) rt[i] = (ok && hasT) ? Pt[off] : 0.f;
+      }
     }
-    __syncthreads();
+  };
+  auto store_op = [&](float (*L)[LDP], float (*Lt)[LDP], bool vec, bool kfast, const float* r,
+                      const float* rt) {
+    if (vec) {
+      if (kfast) {
+        int row = tid >> 2, kk = (tid & 3) * 4;
 #pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          L[kk + i][row] = r[i];
+          if (MODE) Lt[kk + i][row] = rt[i];
+        }
+      } else {
+        int row = (tid & 15) * 4, kk = tid >> 4;
+        *(float4*)&L[kk][row] = make_float4(r[0], r[1], r[2], r[3]);
+        if (MODE) *(float4*)&Lt[kk][row] = make_float4(rt[0], rt[1], rt[2], rt[3]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int e = tid + 256 * i;
+        int kk = kfast ? (e & (BK - 1)) : (e >> 6);
+        int row = kfast ? (e >> 4) : (e & 63);
+        L[kk][row] = r[i];
+        if (MODE) Lt[kk][row] = rt[i];
+      }
+    }
+  };
+  auto load_tile = [&](int k0) {
+    load_op(p.A, p.A_t, hasAt, p.vecA, a_kfast, m0, p.M, p.sAm, p.sAk, k0, ra, rat);
+    load_op(p.B, p.B_t, hasBt, p.vecB, b_kfast, n0, p.N, p.sBn, p.sBk, k0, rb, rbt);
+  };
+  auto store_tile = [&](int buf) {
+    store_op(As[buf], Ats[MODE ? buf : 0], p.vecA, a_kfast, ra, rat);
+    store_op(Bs[buf], Bts[MODE ? buf : 0], p.vecB, b_kfast, rb, rbt);
+  };
+
+  int buf = 0;
+  if (kbeg < kend) { load_tile(kbeg); store_tile(0); }
+  __syncthreads();
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool more = k0 + BK < kend;
+    if (more) load_tile(k0 + BK);          // in flight while this slab is multiplied
+#pragma unroll 4
     for (int kk = 0; kk < BK; ++kk) {
-      float4 a = *(const float4*)&As[kk][tm];
-      float4 b = *(const float4*)&Bs[kk][tn];
+      float4 a = *(const float4*)&As[buf][kk][tm];
+      float4 b = *(const float4*)&Bs[buf][kk][tn];
       float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
       if (MODE == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+        if (do_rs) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) rs[i] += av[i];
+        }
       } else {
-        float4 at = *(const float4*)&Ats[kk][tm];
-        float4 bt = *(const float4*)&Bts[kk][tn];
+        float4 at = *(const float4*)&Ats[buf][kk][tm];
+        float4 bt = *(const float4*)&Bts[buf][kk][tn];
         float atv[4] = {at.x, at.y, at.z, at.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             acc[i][j] = fmaf(av[i], btv[j], fmaf(atv[i], bv[j], acc[i][j]));
+        if (do_rs) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) rs[i] += atv[i];
+        }
       }
     }
+    if (more) store_tile(buf ^ 1);
     __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- split-K: fp32 atomics into this tile's (always-zero-between-launches) scratch accumulator;
+  // the last block to arrive swaps the sums out (re-zeroing the scratch) and runs the epilogue.
+  // No device-scope fence: on gfx950 that is a whole-L2 write-back + invalidate per block.  The
+  // accumulators are only ever touched by device-scope atomics, and a wave's atomics are acknowledged
+  // (s_waitcnt vmcnt(0), part of the barrier) before thread 0 bumps the arrival counter.
+  if (p.splits > 1) {
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+    float* mine = p.part + (size_t)tile * (BM * BN) + tid;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) atomicAdd(mine + (i * 4 + j) * 256, acc[i][j]);
+    float* rsp = p.part_rs + (size_t)blockIdx.y * BM + tm;
+    if (do_rs && (tid & 15) == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) atomicAdd(rsp + i, rs[i]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) {
+      unsigned prev = atomicAdd(&p.ctr[tile], 1u);
+      s_last = prev == (unsigned)(p.splits - 1);
+      if (s_last) atomicExch(&p.ctr[tile], 0u);   // ready for the next launch on this stream
+    }
+    __syncthreads();
+    if (!s_last) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = atomicExch(mine + (i * 4 + j) * 256, 0.f);
+    if (do_rs && (tid & 15) == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rs[i] = atomicExch(rsp + i, 0.f);
+    }
+  }
+
+  // ---- epilogue
+  if (do_rs && (tid & 15) == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (m0 + tm + i < p.M) p.rowsum[m0 + tm + i] = rs[i];
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int m = m0 + tm + i;
     if (m >= p.M) continue;
+    float o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       int n = n0 + tn + j;
-      if (n >= p.N) continue;
-      float* dst = p.C + (int64_t)m * p.N + n;
-      if (p.atomic) atomicAdd(dst, acc[i][j]);
-      else *dst = acc[i][j];
+      float v = acc[i][j];
+      if (n < p.N) {
+        if (p.epi == EP_BIAS_ACT) {
+          v += p.bias ? p.bias[n] : 0.f;
+          if (p.act == 1) v = relu_(v);
+          else if (p.act == 2) v = sigmoid_(v);
+        } else if (p.epi == EP_BIAS_ACT_T) {
+          // aux holds the stashed POST-activation primal; recover what the tangent rule needs from it
+          v += p.bias ? p.bias[n] : 0.f;
+          float yv = p.aux ? p.aux[(int64_t)m * p.N + n] : 0.f;
+          float d = p.act == 1 ? (yv > 0.f ? 1.f : 0.f) : (p.act == 2 ? yv * (1.f - yv) : 1.f);
+          v *= d;
+        } else if (p.epi == EP_RELU_MASK) {
+          v = p.aux[(int64_t)m * p.N + n] > 0.f ? v : 0.f;
+        }
+      }
+      o[j] = v;
+    }
+    float* dst = p.C + (int64_t)m * p.N + n0 + tn;
+    if (p.vecC && n0 + tn + 3 < p.N) {
+      *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n0 + tn + j < p.N) dst[j] = o[j];
     }
   }
 }
 
-template <class S> DEVI S ldz(const float* pv, const float* pt, size_t i) {
-  if constexpr (IsDual<S>::v) return Dual(pv[i], pt ? pt[i] : 0.f);
-  else return pv[i];
-}
-// y = act(acc + b)    acc: primal GEMM result in y (MODE 0) / tangent GEMM result in y_t (MODE 1)
-template <class S>
-__global__ void k_bias_act(float* __restrict__ y, float* __restrict__ y_t,
-                           const float* __restrict__ b, const float* __restrict__ b_t, int n, int j,
-                           int act) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)n * j;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    int jj = (int)(i % j);
-    S s;
-    if constexpr (IsDual<S>::v) {
-      // y holds the stashed POST-activation primal; recover what the tangent rule needs from it
-      float yt = y_t[i] + (b_t ? b_t[jj] : 0.f);
-      float yv = y[i];
-      float d = act == 1 ? (yv > 0.f ? 1.f : 0.f) : (act == 2 ? yv * (1.f - yv) : 1.f);
-      y_t[i] = d * yt;
-      continue;
-    } else {
-      s = y[i] + (b ? b[jj] : 0.f);
-      if (act == 1) s = relu_(s);
-      else if (act == 2) s = sigmoid_(s);
-      y[i] = s;
-    }
-  }
-}
-// db[j] = sum_n dy[n,j]   (tangent: of dy_t)
-__global__ void k_colsum(float* __restrict__ db, const float* __restrict__ dy, int n, int j) {
-  int jj = blockIdx.x * blockDim.x + threadIdx.x;
-  if (jj >= j) return;
-  float s = 0.f;
-  for (int nn = 0; nn < n; ++nn) s += dy[(size_t)nn * j + jj];
-  db[jj] = s;
-}
+inline bool al16(const void* p) { return p == nullptr || ((uintptr_t)p & 15) == 0; }
 
 void run_gemm(bool tangent, const float* A, const float* A_t, const float* B, const float* B_t,
               float* C, int M, int N, int K, int64_t sAm, int64_t sAk, int64_t sBk, int64_t sBn,
-              hipStream_t st) {
+              int epi, int act, const float* bias, const float* aux, float* rowsum,
+              const LinScratch& ws, hipStream_t st) {
   GArgs g;
   g.A = A; g.A_t = A_t; g.B = B; g.B_t = B_t; g.C = C; g.M = M; g.N = N; g.K = K;
   g.sAm = sAm; g.sAk = sAk; g.sBk = sBk; g.sBn = sBn;
-  int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  g.epi = epi; g.act = act; g.bias = bias; g.aux = aux; g.rowsum = rowsum;
+  g.part = ws.part; g.part_rs = ws.part_rs; g.ctr = ws.ctr;
+  // 16-byte loads run along the unit-stride dimension and must not straddle the operand's edge
+  g.vecA = al16(A) && al16(A_t) && (sAk == 1 ? (sAm % 4 == 0 && K % 4 == 0) : (sAm == 1 && sAk % 4 == 0 && M % 4 == 0));
+  g.vecB = al16(B) && al16(B_t) && (sBk == 1 ? (sBn % 4 == 0 && K % 4 == 0) : (sBn == 1 && sBk % 4 == 0 && N % 4 == 0));
+  g.vecC = al16(C) && N % 4 == 0;
+  int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
+  int tiles = mt * nt;
   int splits = 1;
-  if (tiles < 256) {
+  if (tiles < 256 && ws.part) {
     splits = (512 + tiles - 1) / tiles;
     int maxs = (K + 4 * BK - 1) / (4 * BK);   // at least 4 K-steps per block
     if (splits > maxs) splits = maxs;
+    if (tiles > ws.ctr_n || (int64_t)tiles * BM * BN > ws.part_floats ||
+        (int64_t)mt * BM > ws.part_rs_floats) splits = 1;
     if (splits < 1) splits = 1;
   }
   int len = (K + splits - 1) / splits;
   len = (len + BK - 1) / BK * BK;
-  splits = (K + len - 1) / len;
+  if (len < BK) len = BK;
+  splits = std::max(1, (K + len - 1) / len);
   g.ksplit_len = len;
-  g.atomic = splits > 1;
-  if (g.atomic) (void)hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), st);
-  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, splits);
+  g.splits = splits;
+  dim3 grid(nt, mt, splits);
   if (tangent) k_sgemm_small<1><<<grid, 256, 0, st>>>(g);
   else k_sgemm_small<0><<<grid, 256, 0, st>>>(g);
 }
 
 }  // namespace
 
+int64_t lin_scratch_bytes() {
+  return (LIN_PART_FLOATS + LIN_PART_RS_FLOATS) * 4 + LIN_CTR_N * 4;
+}
+LinScratch lin_scratch_carve(void* base) {
+  LinScratch s;
+  s.part = (float*)base; s.part_floats = LIN_PART_FLOATS;
+  s.part_rs = s.part + LIN_PART_FLOATS; s.part_rs_floats = LIN_PART_RS_FLOATS;
+  s.ctr = (unsigned*)(s.part_rs + LIN_PART_RS_FLOATS); s.ctr_n = LIN_CTR_N;
+  return s;
+}
+
 // y[n,j] = act(sum_k x[n,k] W[j,k] + b[j])
 void launch_linear_fwd(float* y, float* y_t, const float* x, const float* x_t, const float* W,
                        const float* W_t, const float* b, const float* b_t, int n, int k, int j,
-                       int act, hipStream_t st) {
-  int grid = (int)std::min<int64_t>(((int64_t)n * j + 255) / 256, 2048);
-  if (y_t) {
-    run_gemm(true, x, x_t, W, W_t, y_t, n, j, k, k, 1, 1, k, st);
-    k_bias_act<Dual><<<grid, 256, 0, st>>>(y, y_t, b, b_t, n, j, act);
-  } else {
-    run_gemm(false, x, nullptr, W, nullptr, y, n, j, k, k, 1, 1, k, st);
-    k_bias_act<float><<<grid, 256, 0, st>>>(y, nullptr, b, nullptr, n, j, act);
-  }
+                       int act, const LinScratch& ws, hipStream_t st) {
+  if (y_t) run_gemm(true, x, x_t, W, W_t, y_t, n, j, k, k, 1, 1, k, EP_BIAS_ACT_T, act, b_t, y, nullptr, ws, st);
+  else run_gemm(false, x, nullptr, W, nullptr, y, n, j, k, k, 1, 1, k, EP_BIAS_ACT, act, b, nullptr, nullptr, ws, st);
 }
-// dx[n,k] = sum_j dy[n,j] W[j,k]
+// dx[n,k] = sum_j dy[n,j] W[j,k]   (* [relu_of > 0] when given: the ReLU backward of the SE MLP)
 void launch_linear_dgrad(float* dx, float* dx_t, const float* dy, const float* dy_t,
-                         const float* W, const float* W_t, int n, int k, int j, hipStream_t st) {
-  if (dx_t) run_gemm(true, dy, dy_t, W, W_t, dx_t, n, k, j, j, 1, k, 1, st);
-  else run_gemm(false, dy, nullptr, W, nullptr, dx, n, k, j, j, 1, k, 1, st);
+                         const float* W, const float* W_t, const float* relu_of, int n, int k,
+                         int j, const LinScratch& ws, hipStream_t st) {
+  int epi = relu_of ? EP_RELU_MASK : EP_PLAIN;
+  if (dx_t) run_gemm(true, dy, dy_t, W, W_t, dx_t, n, k, j, j, 1, k, 1, epi, 0, nullptr, relu_of, nullptr, ws, st);
+  else run_gemm(false, dy, nullptr, W, nullptr, dx, n, k, j, j, 1, k, 1, epi, 0, nullptr, relu_of, nullptr, ws, st);
 }
 // dW[j,k] = sum_n dy[n,j] x[n,k] ; db[j] = sum_n dy[n,j]   (tangent pass writes tangents only)
 void launch_linear_wgrad(float* dW, float* db, const float* dy, const float* dy_t, const float* x,
-                         const float* x_t, int n, int k, int j, hipStream_t st) {
+                         const float* x_t, int n, int k, int j, const LinScratch& ws,
+                         hipStream_t st) {
   bool tangent = dy_t || x_t;
-  if (tangent) run_gemm(true, dy, dy_t, x, x_t, dW, j, k, n, 1, j, k, 1, st);
-  else run_gemm(false, dy, nullptr, x, nullptr, dW, j, k, n, 1, j, k, 1, st);
-  if (db) {
-    if (tangent && !dy_t) (void)hipMemsetAsync(db, 0, (size_t)j * sizeof(float), st);
-    else k_colsum<<<(j + 255) / 256, 256, 0, st>>>(db, tangent ? dy_t : dy, n, j);
-  }
+  if (tangent) run_gemm(true, dy, dy_t, x, x_t, dW, j, k, n, 1, j, k, 1, EP_PLAIN, 0, nullptr, nullptr, db, ws, st);
+  else run_gemm(false, dy, nullptr, x, nullptr, dW, j, k, n, 1, j, k, 1, EP_PLAIN, 0, nullptr, nullptr, db, ws, st);
 }
