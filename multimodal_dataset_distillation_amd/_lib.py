@@ -73,11 +73,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("MDD_HIP_LIB", LIB_PATH)   # kernel-variant experiments (tools/variants.sh)
+    if not os.path.exists(path):
         raise RuntimeError(
             "libmdd_hip.so is not built (%s). Run `python -m multimodal_dataset_distillation_amd."
-            "build_ext` (needs hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+            "build_ext` (needs hipcc, gfx950). There is no CPU fallback." % path)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
         fn.restype = res

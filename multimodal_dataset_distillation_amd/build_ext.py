@@ -28,6 +28,35 @@ def _digest(paths):
     return h.hexdigest()
 
 
+def build_variant(tag, defines, verbose=True):
+    """Experiment build: every source compiled with extra -D flags into variants/libmdd_hip.<tag>.so
+    (selected at run time with MDD_HIP_LIB=...).  Not used by the product path."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    vdir = os.path.join(HERE, "variants")
+    odir = os.path.join(vdir, "_obj_" + tag)
+    os.makedirs(odir, exist_ok=True)
+    flags = FLAGS + ["-D" + d for d in defines]
+
+    def one(s):
+        obj = os.path.join(odir, s + ".o")
+        r = subprocess.run([hipcc] + flags + ["-c", os.path.join(CSRC, s), "-o", obj],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s" % (s, r.stderr[-6000:]))
+        return obj
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(one, SOURCES))
+    lib = os.path.join(vdir, "libmdd_hip.%s.so" % tag)
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs,
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+    if verbose:
+        print("[build] variant", lib, flush=True)
+    return lib
+
+
 def build(verbose=True, force=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
@@ -70,4 +99,7 @@ def build(verbose=True, force=False):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":   # --variant TAG DEF1 DEF2=3 ...
+        build_variant(sys.argv[2], sys.argv[3:])
+    else:
+        build(force="--force" in sys.argv)

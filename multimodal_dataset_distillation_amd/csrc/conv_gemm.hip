@@ -20,6 +20,13 @@
 
 #include "kernels.h"
 
+#ifndef MDD_EPI_UNROLL
+#define MDD_EPI_UNROLL 4
+#endif
+#ifndef MDD_BIG_TILE
+#define MDD_BIG_TILE 0
+#endif
+
 namespace {
 
 typedef unsigned __attribute__((ext_vector_type(4))) u32x4;   // first-class 16-byte register value
@@ -339,56 +346,75 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
         bias[e] = b4.x; bias[e + 1] = b4.y; bias[e + 2] = b4.z; bias[e + 3] = b4.w;
       }
     }
-    auto ld = [&](const AT* ptr, size_t idx, float* f) { Chunk<AT>::unpack(*(const uint4*)(ptr + idx), f); };
-    auto st = [&](AT* ptr, size_t idx, const float* f) { *(uint4*)(ptr + idx) = Chunk<AT>::pack(f); };
-#pragma unroll 4
-    for (int ps = 0; ps < WROWS / RPP; ++ps) {
-      const int row = ps * RPP + lrow;
-      int m = m0 + wm * WROWS + row;
-      if (m >= e_M) continue;
-      if constexpr (MODE == 2) {   // class-local pixel -> full-resolution output pixel
-        int oxc = m % e_wo, t = m / e_wo;
-        int oyc = t % e_ho, ni = t / e_ho;
-        m = (ni * G.ho + 2 * oyc + py) * G.wo + 2 * oxc + px;
-      }
-      const size_t idx = (size_t)m * G.co_tot + ch;
-      float v[CE], t0[CE], t1[CE], t2[CE], o[CE];
+    // The output pointers may alias the stashed operands as far as the compiler can tell, so it
+    // will not hoist the loads of pass p+1 above the stores of pass p by itself: the loop is
+    // software-pipelined by hand -- all global loads of U passes are issued first (one 16-byte load
+    // per operand and pass in flight per lane), then the U passes are computed and stored.
+    constexpr int NP = WROWS / RPP;
+    constexpr int U = NP < MDD_EPI_UNROLL ? NP : MDD_EPI_UNROLL;
+    const int mode = E.mode;
+    const bool need_c = out_act && mode != EPI_FWD;
+    const bool need_t = out_act && mode == EPI_BWD_T;
+    const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll 1
+    for (int ps0 = 0; ps0 < NP; ps0 += U) {
+      size_t idx[U];
+      bool ok[U];
+      uint4 q_a1[U], q_c[U], q_ct[U], q_ab[U], q_a2[U];
 #pragma unroll
-      for (int e = 0; e < CE; e += 4) {
-        float4 s4 = *(const float4*)(stage + row * PITCH + lcol + e);
-        v[e] = s4.x + bias[e]; v[e + 1] = s4.y + bias[e + 1];
-        v[e + 2] = s4.z + bias[e + 2]; v[e + 3] = s4.w + bias[e + 3];
+      for (int u = 0; u < U; ++u) {
+        const int row = (ps0 + u) * RPP + lrow;
+        int m = m0 + wm * WROWS + row;
+        ok[u] = m < e_M;
+        if constexpr (MODE == 2) {   // class-local pixel -> full-resolution output pixel
+          int oxc = m % e_wo, t = m / e_wo;
+          int oyc = t % e_ho, ni = t / e_ho;
+          m = (ni * G.ho + 2 * oyc + py) * G.wo + 2 * oxc + px;
+        }
+        idx[u] = (size_t)m * G.co_tot + ch;
+        q_a1[u] = (ok[u] && add1) ? *(const uint4*)(add1 + idx[u]) : z4;
+        q_c[u] = (ok[u] && need_c) ? *(const uint4*)(Cst + idx[u]) : z4;
+        q_ct[u] = (ok[u] && need_t) ? *(const uint4*)(Ct + idx[u]) : z4;
+        q_ab[u] = (ok[u] && need_t) ? *(const uint4*)(Ab + idx[u]) : z4;
+        q_a2[u] = (ok[u] && out_act && add2) ? *(const uint4*)(add2 + idx[u]) : z4;
       }
-      if (add1) {
-        ld(add1, idx, t0);
 #pragma unroll
-        for (int e = 0; e < CE; ++e) v[e] += t0[e];
-      }
-      if (out_raw && !(p.dbg & 2)) st(out_raw, idx, v);
-      if (!out_act) continue;
-      switch (E.mode) {
-        case EPI_FWD:
+      for (int u = 0; u < U; ++u) {
+        if (!ok[u]) continue;
+        const int row = (ps0 + u) * RPP + lrow;
+        float v[CE], t0[CE], t1[CE], t2[CE], o[CE];
+#pragma unroll
+        for (int e = 0; e < CE; e += 4) {
+          float4 s4 = *(const float4*)(stage + row * PITCH + lcol + e);
+          v[e] = s4.x + bias[e]; v[e + 1] = s4.y + bias[e + 1];
+          v[e + 2] = s4.z + bias[e + 2]; v[e + 3] = s4.w + bias[e + 3];
+        }
+        if (add1) {
+          Chunk<AT>::unpack(q_a1[u], t0);
+#pragma unroll
+          for (int e = 0; e < CE; ++e) v[e] += t0[e];
+        }
+        if (out_raw && !(p.dbg & 2)) *(uint4*)(out_raw + idx[u]) = Chunk<AT>::pack(v);
+        if (!out_act) continue;
+        if (mode == EPI_FWD) {
 #pragma unroll
           for (int e = 0; e < CE; ++e) o[e] = E.beta * silu_(v[e]);
-          break;
-        case EPI_FWD_T:
-        case EPI_BWD:
-          ld(Cst, idx, t0);
-#pragma unroll
-          for (int e = 0; e < CE; ++e) o[e] = E.beta * dsilu_(t0[e]) * v[e];
-          break;
-        default:  // EPI_BWD_T
-          ld(Cst, idx, t0); ld(Ct, idx, t1); ld(Ab, idx, t2);
+        } else if (mode == EPI_BWD_T) {
+          Chunk<AT>::unpack(q_c[u], t0); Chunk<AT>::unpack(q_ct[u], t1); Chunk<AT>::unpack(q_ab[u], t2);
 #pragma unroll
           for (int e = 0; e < CE; ++e) o[e] = E.beta * (dsilu_(Dual(t0[e], t1[e])) * Dual(t2[e], v[e])).t;
-          break;
-      }
-      if (add2) {
-        ld(add2, idx, t0);
+        } else {   // EPI_FWD_T, EPI_BWD
+          Chunk<AT>::unpack(q_c[u], t0);
 #pragma unroll
-        for (int e = 0; e < CE; ++e) o[e] += t0[e];
+          for (int e = 0; e < CE; ++e) o[e] = E.beta * dsilu_(t0[e]) * v[e];
+        }
+        if (add2) {
+          Chunk<AT>::unpack(q_a2[u], t0);
+#pragma unroll
+          for (int e = 0; e < CE; ++e) o[e] += t0[e];
+        }
+        if (!(p.dbg & 2)) *(uint4*)(out_act + idx[u]) = Chunk<AT>::pack(o);
       }
-      if (!(p.dbg & 2)) st(out_act, idx, o);
     }
   }
 }
@@ -444,7 +470,13 @@ void launch_conv_gemm(const ConvGeom& g, const AT* A1, const AT* B1, const AT* A
   } while (0)
   if (g.nc <= 32) MDD_DISPATCH(4, 1, 1, 1);        // 128 x 32  (stem)
   else if (g.nc <= 64) MDD_DISPATCH(4, 1, 2, 2);   // 256 x 64  (group width 64)
+#if MDD_BIG_TILE == 0
   else MDD_DISPATCH(2, 2, 2, 2);                   // 128 x 128
+#elif MDD_BIG_TILE == 1
+  else MDD_DISPATCH(4, 1, 1, 2);                   // 128 x 64
+#else
+  else MDD_DISPATCH(2, 2, 1, 2);                   // 64 x 128
+#endif
 #undef MDD_DISPATCH
 }
 template void launch_conv_gemm<float>(const ConvGeom&, const float*, const float*, const float*,
