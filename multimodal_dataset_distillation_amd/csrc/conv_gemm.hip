@@ -26,6 +26,12 @@
 #ifndef MDD_BIG_TILE
 #define MDD_BIG_TILE 0
 #endif
+#ifndef MDD_SINGLE_BUF
+#define MDD_SINGLE_BUF 1
+#endif
+#ifndef MDD_MIN_WAVES
+#define MDD_MIN_WAVES 3
+#endif
 
 namespace {
 
@@ -69,13 +75,12 @@ struct KArgs {
 };
 
 template <class AT, int WGM, int WGN, int TM, int TN, int MODE, bool KFULL>
-__global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
+__global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   constexpr int RA = BM / 32, RB = BN / 32;
   constexpr int KE = Mma<AT>::KE, CE = Mma<AT>::CE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* As = smem;                 // 2 * BM * 128
-  char* Bs = smem + 2 * BM * 128;  // 2 * BN * 128
+  constexpr int NBUF = MDD_SINGLE_BUF ? 1 : 2;   // LDS stages (registers hold the slab in flight)
 
   const ConvGeom& G = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
   // LDS byte addresses.  Rows 32 apart share the swizzle, so the i / j sub-tiles are reached with
   // immediate offsets (i * 4096) from ONE register per q; the double buffer is toggled by XOR-ing
   // one bit into these few registers per K-step (buffer strides are powers of two).
-  constexpr int ABUF = BM * 128, BBUF = BN * 128, BBASE = 2 * BM * 128;
+  constexpr int ABUF = NBUF == 2 ? BM * 128 : 0, BBUF = NBUF == 2 ? BN * 128 : 0, BBASE = NBUF * BM * 128;
   const int l31 = lane & 31, lh = lane >> 5;
   int rdA[4], rdB[4];
 #pragma unroll
@@ -301,6 +306,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) load_tile(kt + 1, s0);
     compute();
+    if (NBUF == 1) __syncthreads();      // everyone is done reading the slab before it is replaced
     if (kt + 1 < nk) store_tile(s0);
     __syncthreads();
   }
@@ -313,16 +319,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
   constexpr int LPR = WCOLS / CE;      // lanes per output row
   constexpr int RPP = 64 / LPR;        // rows per pass
   if (p.dbg & 4) return;   // dbg bit2: no epilogue at all (timing only)
-  float* stage = (float*)smem + wave * (WROWS * PITCH);
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + j * 32 + l31] = acc[i][j][r];
-  __syncthreads();
-
+  float* stage = (float*)smem + wave * (32 * PITCH);   // one 32-row MFMA block at a time
   const ConvEpi& E = p.ep;
   AT* out_raw = (AT*)E.out_raw;
   AT* out_act = (AT*)E.out_act;
@@ -333,29 +330,41 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
   const AT* add2 = (const AT*)E.add2;
   const int lrow = lane / LPR, lcol = (lane % LPR) * CE;
   const int n = n0 + wn * WCOLS + lcol;
-  if (n < G.nc) {
-    const int ch = grp * G.nc + n;
-    float bias[CE];
+  const bool ncol_ok = n < G.nc;
+  const int ch = grp * G.nc + n;
+  float bias[CE];
 #pragma unroll
-    for (int e = 0; e < CE; ++e) bias[e] = 0.f;
-    const float* bp = E.mode == EPI_FWD ? E.bias : (E.mode == EPI_FWD_T ? E.bias_t : nullptr);
-    if (bp) {
+  for (int e = 0; e < CE; ++e) bias[e] = 0.f;
+  const float* bp = E.mode == EPI_FWD ? E.bias : (E.mode == EPI_FWD_T ? E.bias_t : nullptr);
+  if (bp && ncol_ok) {
 #pragma unroll
-      for (int e = 0; e < CE; e += 4) {
-        float4 b4 = *(const float4*)(bp + ch + e);
-        bias[e] = b4.x; bias[e + 1] = b4.y; bias[e + 2] = b4.z; bias[e + 3] = b4.w;
-      }
+    for (int e = 0; e < CE; e += 4) {
+      float4 b4 = *(const float4*)(bp + ch + e);
+      bias[e] = b4.x; bias[e + 1] = b4.y; bias[e + 2] = b4.z; bias[e + 3] = b4.w;
     }
-    // The output pointers may alias the stashed operands as far as the compiler can tell, so it
-    // will not hoist the loads of pass p+1 above the stores of pass p by itself: the loop is
-    // software-pipelined by hand -- all global loads of U passes are issued first (one 16-byte load
-    // per operand and pass in flight per lane), then the U passes are computed and stored.
-    constexpr int NP = WROWS / RPP;
-    constexpr int U = NP < MDD_EPI_UNROLL ? NP : MDD_EPI_UNROLL;
-    const int mode = E.mode;
-    const bool need_c = out_act && mode != EPI_FWD;
-    const bool need_t = out_act && mode == EPI_BWD_T;
-    const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+  }
+  // The output pointers may alias the stashed operands as far as the compiler can tell, so it
+  // will not hoist the loads of pass p+1 above the stores of pass p by itself: the loop is
+  // software-pipelined by hand -- all global loads of U passes are issued first (one 16-byte load
+  // per operand and pass in flight per lane), then the U passes are computed and stored.
+  constexpr int NP = 32 / RPP;
+  constexpr int U = NP < MDD_EPI_UNROLL ? NP : MDD_EPI_UNROLL;
+  const int mode = E.mode;
+  const bool need_c = out_act && mode != EPI_FWD;
+  const bool need_t = out_act && mode == EPI_BWD_T;
+  const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+  for (int hi = 0; hi < TM; ++hi) {
+    // this wave's 32-row block hi of the accumulators -> its private LDS stage (aliases the K-loop
+    // buffers: the loop's final barrier has retired every read of them)
+    if (hi) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + j * 32 + l31] = acc[hi][j][r];
+    __syncthreads();
+    if (!ncol_ok) continue;
 #pragma unroll 1
     for (int ps0 = 0; ps0 < NP; ps0 += U) {
       size_t idx[U];
@@ -364,7 +373,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const KArgs p) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int row = (ps0 + u) * RPP + lrow;
-        int m = m0 + wm * WROWS + row;
+        int m = m0 + wm * WROWS + hi * 32 + row;
         ok[u] = m < e_M;
         if constexpr (MODE == 2) {   // class-local pixel -> full-resolution output pixel
           int oxc = m % e_wo, t = m / e_wo;
@@ -427,8 +436,8 @@ void launch_cfg(const KArgs& a, hipStream_t st) {
   k.mtiles = (a.M + BM - 1) / BM;
   if (MODE == 2) k.mtiles = 4 * ((a.g.nimg * (a.g.ho / 2) * (a.g.wo / 2) + BM - 1) / BM);
   k.ntiles = (a.g.nc + BN - 1) / BN;
-  size_t shm = 2 * (BM + BN) * 128;
-  size_t shm_epi = 4 * (size_t)(TM * 32) * (TN * 32 + 4) * sizeof(float);  // per-wave transpose
+  size_t shm = (MDD_SINGLE_BUF ? 1 : 2) * (BM + BN) * 128;
+  size_t shm_epi = 4 * (size_t)32 * (TN * 32 + 4) * sizeof(float);  // per-wave transpose, 32 rows at a time
   if (shm_epi > shm) shm = shm_epi;
   static bool attr_set = false;
   if (!attr_set) {
