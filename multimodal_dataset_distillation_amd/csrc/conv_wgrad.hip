@@ -21,6 +21,13 @@
 
 #include "kernels.h"
 
+#ifndef MDD_WG_SINGLE_BUF
+#define MDD_WG_SINGLE_BUF 1
+#endif
+#ifndef MDD_WG_MIN_WAVES
+#define MDD_WG_MIN_WAVES 1
+#endif
+
 namespace {
 
 struct WArgs {
@@ -38,7 +45,7 @@ DEVI uint4 mask4(uint4 v, bool keep) {
 template <int ROWB> DEVI int wswz(int row) { return ROWB == 128 ? ((row >> 1) & 3) : (row & 7); }
 
 template <class AT, int BCO, int BKP, int BKM>
-__global__ __launch_bounds__(256) void k_conv_wgrad(const WArgs p) {
+__global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArgs p) {
   constexpr int CE = 16 / (int)sizeof(AT);
   constexpr bool BF = sizeof(AT) == 2;
   constexpr int DCH = BCO / CE, XCH = BKP / CE;          // chunks per row
@@ -50,9 +57,10 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const WArgs p) {
   constexpr int WKW = BKP / WKP;                         // k' width per wave
   static_assert(DSL >= 1 && XSL >= 1, "tile too small for 256 threads");
   static_assert(BF || (BCO == 64 && BKP == 128), "f32 path: 64x128 tile only");
-  __shared__ __attribute__((aligned(16))) char smem[2 * (DTILE + XTILE)];
+  constexpr int NBUF = MDD_WG_SINGLE_BUF ? 1 : 2;   // LDS stages (registers hold the tile in flight)
+  __shared__ __attribute__((aligned(16))) char smem[NBUF * (DTILE + XTILE)];
   char* Ds = smem;
-  char* Xs = smem + 2 * DTILE;
+  char* Xs = smem + NBUF * DTILE;
 
   const ConvGeom& G = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const WArgs p) {
   __syncthreads();
 
   for (int it = 0; it < niter; ++it) {
-    const int buf = it & 1;
+    const int buf = NBUF == 2 ? (it & 1) : 0;
     if (it + 1 < niter) load_tile(it + 1);
     const char* d = Ds + buf * DTILE;
     const char* x = Xs + buf * XTILE;
@@ -243,7 +251,8 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const WArgs p) {
           }
       }
     }
-    if (it + 1 < niter) store_tile(buf ^ 1);
+    if (NBUF == 1) __syncthreads();      // everyone is done reading the tile before it is replaced
+    if (it + 1 < niter) store_tile(NBUF == 2 ? (buf ^ 1) : 0);
     __syncthreads();
   }
 

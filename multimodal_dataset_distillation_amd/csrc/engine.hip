@@ -18,6 +18,7 @@
 #include <type_traits>
 #include <algorithm>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "kernels.h"
@@ -535,14 +536,27 @@ struct Eng : mdd_engine {
       else gemm(L, g, in, wf_t + L.off_p, nullptr, nullptr, e, st);
     }
   }
-  // weight + bias gradient of conv L (dy = grad wrt its raw output, x = its input)
-  void conv_bwd_w(bool T, const ConvL& L, const AT* dy, const AT* dy_t, const AT* x, const AT* x_t,
-                  float* dwf_, float* dwf_t_, float* gout, hipStream_t st) {
-    ConvGeom g = gfwd(L);
+  // Weight-gradient work is queued while a block's data-gradient chain is enqueued on the main
+  // stream and released to the side stream with ONE event per block (flush_w): an event record is a
+  // barrier packet on the main queue (~8-12 us bubble each), and nothing on the main stream waits for
+  // these results before the end of the pass.
+  std::vector<std::function<void(hipStream_t)>> wq;
+  void flush_w(hipStream_t st) {
+    if (wq.empty()) return;
     fork(st);
     hipStream_t ws_ = wstream(st);
-    if (!T) wgrad(L, g, dy, x, nullptr, nullptr, dwf_ + L.off_p, gout + L.off_b, ws_);
-    else wgrad(L, g, dy_t, x, x_t ? dy : nullptr, x_t, dwf_t_ + L.off_p, gout + L.off_b, ws_);
+    for (auto& f : wq) f(ws_);
+    wq.clear();
+  }
+  // weight + bias gradient of conv L (dy = grad wrt its raw output, x = its input)
+  void conv_bwd_w(bool T, const ConvL& L, const AT* dy, const AT* dy_t, const AT* x, const AT* x_t,
+                  float* dwf_, float* dwf_t_, float* gout, hipStream_t) {
+    const ConvL* Lp = &L;
+    wq.push_back([=](hipStream_t ws_) {
+      ConvGeom g = gfwd(*Lp);
+      if (!T) wgrad(*Lp, g, dy, x, nullptr, nullptr, dwf_ + Lp->off_p, gout + Lp->off_b, ws_);
+      else wgrad(*Lp, g, dy_t, x, x_t ? dy : nullptr, x_t, dwf_t_ + Lp->off_p, gout + Lp->off_b, ws_);
+    });
   }
   // data gradient of conv L with fused epilogue
   void conv_bwd_d(bool T, const ConvL& L, const AT* dy, const AT* dy_t, ConvEpi e, hipStream_t st) {
@@ -656,11 +670,17 @@ struct Eng : mdd_engine {
       launch_linear_dgrad(oa.hB, T ? qa.hB : nullptr, oa.zB, T ? qa.zB : nullptr,
                           th + B.se.off_w2, T ? th_t + B.se.off_w2 : nullptr, pa.h, N, rd, c,
                           lin_main, st);
-      fork(st);
-      launch_linear_wgrad(gout + B.se.off_w2, gout + B.se.off_b2, oa.zB, T ? qa.zB : nullptr, pa.h,
-                          T ? qa.h : nullptr, N, rd, c, wlin(), wstream(st));
-      launch_linear_wgrad(gout + B.se.off_w1, gout + B.se.off_b1, oa.hB, T ? qa.hB : nullptr, pa.p,
-                          T ? qa.p : nullptr, N, c, rd, wlin(), wstream(st));
+      {
+        const float *zB = oa.zB, *zB_t = T ? qa.zB : nullptr, *hh = pa.h, *hh_t = T ? qa.h : nullptr;
+        const float *hB = oa.hB, *hB_t = T ? qa.hB : nullptr, *pp = pa.p, *pp_t = T ? qa.p : nullptr;
+        float *gw2 = gout + B.se.off_w2, *gb2 = gout + B.se.off_b2, *gw1 = gout + B.se.off_w1,
+              *gb1 = gout + B.se.off_b1;
+        const int n_ = N;
+        wq.push_back([=](hipStream_t ws_) {
+          launch_linear_wgrad(gw2, gb2, zB, zB_t, hh, hh_t, n_, rd, c, wlin(), ws_);
+          launch_linear_wgrad(gw1, gb1, hB, hB_t, pp, pp_t, n_, c, rd, wlin(), ws_);
+        });
+      }
       launch_linear_dgrad(oa.pB, T ? qa.pB : nullptr, oa.hB, T ? qa.hB : nullptr, th + B.se.off_w1,
                           T ? th_t + B.se.off_w1 : nullptr, nullptr, N, c, rd, lin_main, st);
       launch_se_apply_bwd<AT>(oa.C3B, T ? qa.C3B : nullptr, xb, T ? xb_t : nullptr, pa.gate,
@@ -694,23 +714,29 @@ struct Eng : mdd_engine {
       conv_bwd_d(T, convs[B.c1], oa.C1B, qa.C1B,
                  epi_act(T, oa.AinB, O.XB[b], Q.XB[b], P.X[b], Q.X[b], B.beta, add1,
                          B.ds >= 0 ? nullptr : (T ? xb_t : xb)), st);
+      flush_w(st);
     }
     // stem (conv4 output is the raw stream X[0]; its grad is XB[0])
     conv_bwd_w(T, convs[stem[3]], O.XB[0], Q.XB[0], P.As[2], Q.As[2], dw, dw_t, gout, st);
+    flush_w(st);   // stem: release each weight gradient at once (they are the tail of the pass)
     conv_bwd_d(T, convs[stem[3]], O.XB[0], Q.XB[0],
                epi_act(T, O.AsB[2], O.CsB[2], Q.CsB[2], P.Cs[2], Q.Cs[2], 1.f, nullptr, nullptr), st);
     conv_bwd_w(T, convs[stem[2]], O.CsB[2], Q.CsB[2], P.As[1], Q.As[1], dw, dw_t, gout, st);
+    flush_w(st);   // stem: release each weight gradient at once (they are the tail of the pass)
     conv_bwd_d(T, convs[stem[2]], O.CsB[2], Q.CsB[2],
                epi_act(T, O.AsB[1], O.CsB[1], Q.CsB[1], P.Cs[1], Q.Cs[1], 1.f, nullptr, nullptr), st);
     conv_bwd_w(T, convs[stem[1]], O.CsB[1], Q.CsB[1], P.As[0], Q.As[0], dw, dw_t, gout, st);
+    flush_w(st);   // stem: release each weight gradient at once (they are the tail of the pass)
     conv_bwd_d(T, convs[stem[1]], O.CsB[1], Q.CsB[1],
                epi_act(T, O.AsB[0], O.CsB[0], Q.CsB[0], P.Cs[0], Q.Cs[0], 1.f, nullptr, nullptr), st);
     conv_bwd_w(T, convs[stem[0]], O.CsB[0], Q.CsB[0], P.X0, nullptr, dw, dw_t, gout, st);
+    flush_w(st);   // stem: release each weight gradient at once (they are the tail of the pass)
     if (dimage) {
       AT* x0b = T ? Q.X0B : O.X0B;
       conv_bwd_d(T, convs[stem[0]], O.CsB[0], Q.CsB[0], epi_lin(x0b, nullptr), st);
       launch_img_scatter_grad<AT>(dimage, x0b, idx, coef, mul, N, 3, S, S, 8, st);
     }
+    flush_w(st);
     join(st);
     launch_ws_backward(d_descs, (int)descs.size(), total_rows, th, T ? th_t : nullptr, dw,
                        T ? dw_t : nullptr, gout, st);
