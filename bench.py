@@ -35,7 +35,7 @@ WORKLOADS = {
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
-KIND_NAMES = ["conv_gemm<128x32>", "conv_gemm<256x64>", "conv_gemm<128x128>", "conv_wgrad<64x128>"]
+KIND_NAMES = ["conv_gemm<128x32>", "conv_gemm<256x64>", "conv_gemm<128x128>", "conv_wgrad"]
 
 
 def algorithmic_flops_per_iter(n, syn_steps):
@@ -213,9 +213,14 @@ def main():
             os.makedirs(os.path.dirname(os.path.abspath(args.dump_launches)), exist_ok=True)
             _lib.check(lib.mdd_engine_profile_dump(eng.h, args.dump_launches.encode()))
         lib.mdd_engine_profile(eng.h, 0)
+        # dominant kernel class = most time per iteration.  Its roofline is the one its ALGORITHMIC
+        # arithmetic intensity selects: below the ridge (peak flops / peak HBM bytes) it is HBM-bound.
         dom = max(kinds, key=lambda d: d["ms"])
-        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        peak_tf = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        secs = dom["ms"] * 1e-3
+        tfs = dom["flops"] / secs / 1e12 if secs > 0 else 0.0
+        gbs = dom["bytes"] / secs / 1e9 if secs > 0 else 0.0
+        hbm_bound = dom["bytes"] > 0 and dom["flops"] / dom["bytes"] < peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic_r01.json")
         if os.path.exists(tf):
@@ -223,12 +228,17 @@ def main():
                 traffic = json.load(open(tf)).get(dom["kernel"])
             except Exception:
                 traffic = None
-        result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                              "frac": ach / peak, "traffic": traffic, "kernel": dom["kernel"],
+        result["roofline"] = {"bound": "hbm" if hbm_bound else "mfma",
+                              "achieved": gbs if hbm_bound else tfs,
+                              "peak": PEAK_HBM_GBS if hbm_bound else peak_tf,
+                              "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                              "frac": (gbs / PEAK_HBM_GBS) if hbm_bound else (tfs / peak_tf),
+                              "traffic": traffic, "kernel": dom["kernel"],
                               "avg_launch_ms": dom["ms"] / max(1, dom["launches"]),
                               "launches_per_iter": dom["launches"],
-                              "algorithmic_gbytes_per_s": dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-                              if dom["ms"] > 0 else 0.0}
+                              "algorithmic_bytes_per_launch": dom["bytes"] / max(1, dom["launches"]),
+                              "algorithmic_tflops_per_s": tfs,
+                              "flops_per_byte": dom["flops"] / max(dom["bytes"], 1.0)}
         result["kernels"] = [dict(kernel=d["kernel"], launches=d["launches"], ms=round(d["ms"], 3),
                                   tflops=round(d["flops"] / max(d["ms"], 1e-9) / 1e9, 2),
                                   gbps=round(d["bytes"] / max(d["ms"], 1e-9) / 1e6, 1)) for d in kinds]

@@ -350,8 +350,9 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
   constexpr int NP = 32 / RPP;
   constexpr int U = NP < MDD_EPI_UNROLL ? NP : MDD_EPI_UNROLL;
   const int mode = E.mode;
-  const bool need_c = out_act && mode != EPI_FWD;
-  const bool need_t = out_act && mode == EPI_BWD_T;
+  const bool ldop = !(p.dbg & 8);                          // dbg bit3: no epilogue operand loads (timing only)
+  const bool need_c = ldop && out_act && mode != EPI_FWD;
+  const bool need_t = ldop && out_act && mode == EPI_BWD_T;
   const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
   for (int hi = 0; hi < TM; ++hi) {
@@ -381,11 +382,11 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
           m = (ni * G.ho + 2 * oyc + py) * G.wo + 2 * oxc + px;
         }
         idx[u] = (size_t)m * G.co_tot + ch;
-        q_a1[u] = (ok[u] && add1) ? *(const uint4*)(add1 + idx[u]) : z4;
+        q_a1[u] = (ok[u] && ldop && add1) ? *(const uint4*)(add1 + idx[u]) : z4;
         q_c[u] = (ok[u] && need_c) ? *(const uint4*)(Cst + idx[u]) : z4;
         q_ct[u] = (ok[u] && need_t) ? *(const uint4*)(Ct + idx[u]) : z4;
         q_ab[u] = (ok[u] && need_t) ? *(const uint4*)(Ab + idx[u]) : z4;
-        q_a2[u] = (ok[u] && out_act && add2) ? *(const uint4*)(add2 + idx[u]) : z4;
+        q_a2[u] = (ok[u] && ldop && out_act && add2) ? *(const uint4*)(add2 + idx[u]) : z4;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -405,7 +406,10 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
         }
         if (out_raw && !(p.dbg & 2)) *(uint4*)(out_raw + idx[u]) = Chunk<AT>::pack(v);
         if (!out_act) continue;
-        if (mode == EPI_FWD) {
+        if (p.dbg & 16) {                                  // dbg bit4: no activation math (timing only)
+#pragma unroll
+          for (int e = 0; e < CE; ++e) o[e] = v[e];
+        } else if (mode == EPI_FWD) {
 #pragma unroll
           for (int e = 0; e < CE; ++e) o[e] = E.beta * silu_(v[e]);
         } else if (mode == EPI_BWD_T) {

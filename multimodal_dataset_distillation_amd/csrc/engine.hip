@@ -540,9 +540,15 @@ struct Eng : mdd_engine {
   // stream and released to the side stream with ONE event per block (flush_w): an event record is a
   // barrier packet on the main queue (~8-12 us bubble each), and nothing on the main stream waits for
   // these results before the end of the pass.
+  static constexpr bool MAIN_TAIL = true;
   std::vector<std::function<void(hipStream_t)>> wq;
-  void flush_w(hipStream_t st) {
+  void flush_w(hipStream_t st, bool on_main = false) {
     if (wq.empty()) return;
+    if (on_main) {   // tail of the pass: the side stream is the one lagging, the main stream helps out
+      for (auto& f : wq) f(st);
+      wq.clear();
+      return;
+    }
     fork(st);
     hipStream_t ws_ = wstream(st);
     for (auto& f : wq) f(ws_);
@@ -725,18 +731,18 @@ struct Eng : mdd_engine {
     flush_w(st);   // stem: release each weight gradient at once (they are the tail of the pass)
     conv_bwd_d(T, convs[stem[2]], O.CsB[2], Q.CsB[2],
                epi_act(T, O.AsB[1], O.CsB[1], Q.CsB[1], P.Cs[1], Q.Cs[1], 1.f, nullptr, nullptr), st);
-    conv_bwd_w(T, convs[stem[1]], O.CsB[1], Q.CsB[1], P.As[0], Q.As[0], dw, dw_t, gout, st);
-    flush_w(st);   // stem: release each weight gradient at once (they are the tail of the pass)
     conv_bwd_d(T, convs[stem[1]], O.CsB[1], Q.CsB[1],
                epi_act(T, O.AsB[0], O.CsB[0], Q.CsB[0], P.Cs[0], Q.Cs[0], 1.f, nullptr, nullptr), st);
-    conv_bwd_w(T, convs[stem[0]], O.CsB[0], Q.CsB[0], P.X0, nullptr, dw, dw_t, gout, st);
-    flush_w(st);   // stem: release each weight gradient at once (they are the tail of the pass)
     if (dimage) {
       AT* x0b = T ? Q.X0B : O.X0B;
       conv_bwd_d(T, convs[stem[0]], O.CsB[0], Q.CsB[0], epi_lin(x0b, nullptr), st);
       launch_img_scatter_grad<AT>(dimage, x0b, idx, coef, mul, N, 3, S, S, 8, st);
     }
-    flush_w(st);
+    // the last two weight gradients run on the main stream: at this point the side stream still has
+    // the high-resolution layers' weight gradients queued and would otherwise be waited for
+    conv_bwd_w(T, convs[stem[1]], O.CsB[1], Q.CsB[1], P.As[0], Q.As[0], dw, dw_t, gout, st);
+    conv_bwd_w(T, convs[stem[0]], O.CsB[0], Q.CsB[0], P.X0, nullptr, dw, dw_t, gout, st);
+    flush_w(st, MAIN_TAIL);
     join(st);
     launch_ws_backward(d_descs, (int)descs.size(), total_rows, th, T ? th_t : nullptr, dw,
                        T ? dw_t : nullptr, gout, st);
