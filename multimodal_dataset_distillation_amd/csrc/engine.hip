@@ -146,7 +146,7 @@ struct Eng : mdd_engine {
   int stem[4], fin;
   std::vector<int> xh, xc;  // stream spatial dim / channels: X[b], b = 0..nb
   int64_t packed_total = 0;
-  int total_rows = 0;
+  int total_rows = 0, total_tiles = 0;
   std::vector<WsDesc> descs;
   // text head offsets
   int64_t t_pw, t_pb, t_fw, t_fb, t_lw, t_lb;
@@ -283,7 +283,8 @@ struct Eng : mdd_engine {
     t_lb = add_param(ptxt, "layer_norm.bias", {feat});
     P_txt = off;
     // weight-standardisation descriptors
-    int row = 0;
+    int row = 0, tile = 0;
+    const int tr = ws_tile_rows();
     for (auto& L : convs) {
       WsDesc d; d.off_w = L.off_w; d.off_b = L.off_b; d.off_g = L.off_g;
       d.off_wf = L.off_p; d.off_wt = L.off_p;
@@ -291,11 +292,12 @@ struct Eng : mdd_engine {
       d.cin_pad_g = L.cin_pad / L.groups; d.cout_g = L.cout / L.groups;
       d.scale = nf.gamma / std::sqrt((float)(d.cin_g * d.ksq)); d.eps = nf.eps;
       d.row_start = row; row += L.cout;
+      d.tile_start = tile; tile += d.groups * ((d.cout_g + tr - 1) / tr);
       descs.push_back(d);
       int ce = 16 / (int)sizeof(AT);
       CHECK_ARG(d.cin_pad_g % ce == 0 && d.cout_g % ce == 0, "channel counts must be multiples of the 16-byte chunk");
     }
-    total_rows = row;
+    total_rows = row; total_tiles = tile;
     plan_workspace();
     return 0;
   }
@@ -590,7 +592,7 @@ struct Eng : mdd_engine {
     CHECK_ARG(slot >= 0 && slot < K, "slot out of range");
     ActSet& P = sets[slot]; ActSet& Q = tn;
     int nb = (int)blks.size();
-    launch_ws_forward<AT>(d_descs, (int)descs.size(), total_rows, th, T ? th_t : nullptr, wf, wt,
+    launch_ws_forward<AT>(d_descs, (int)descs.size(), total_rows, total_tiles, th, T ? th_t : nullptr, wf, wt,
                           wf_t, wt_t, st);
     if (!T) launch_img_gather_nhwc<AT>(P.X0, image, idx, N, 3, S, S, 8, st);
     const AT* in = P.X0; const AT* in_t = nullptr;
@@ -652,7 +654,7 @@ struct Eng : mdd_engine {
     ActSet& O = (!T && !stash) ? tn : P;  // where primal backward signals are written
     int nb = (int)blks.size();
     if (repack)
-      launch_ws_forward<AT>(d_descs, (int)descs.size(), total_rows, th, T ? th_t : nullptr, wf, wt,
+      launch_ws_forward<AT>(d_descs, (int)descs.size(), total_rows, total_tiles, th, T ? th_t : nullptr, wf, wt,
                             wf_t, wt_t, st);
     float* dw = O.dwf; float* dw_t = Q.dwf;
     HIP_CHECK_RET(hipMemsetAsync(T ? dw_t : dw, 0, packed_total * 4, st));

@@ -32,11 +32,13 @@ struct WsDesc {
   int cout, cin_g, ksq, groups, cin_pad_g, cout_g;
   float scale, eps;
   int row_start;                // prefix sum of cout (global row id of this conv's channel 0)
+  int tile_start;               // prefix sum of groups * ceil(cout_g / ws_tile_rows()) (ws_forward blocks)
 };
+int ws_tile_rows();
 // theta_t == nullptr: primal (writes wf, wt).  theta_t != nullptr: tangent pass (writes wf_t,
 // wt_t, and re-derives the primal wf, wt from theta when those pointers are non-null).
 template <class AT>
-void launch_ws_forward(const WsDesc* descs_dev, int nconv, int total_rows, const float* theta,
+void launch_ws_forward(const WsDesc* descs_dev, int nconv, int total_rows, int total_tiles, const float* theta,
                        const float* theta_t, AT* wf, AT* wt, AT* wf_t, AT* wt_t, hipStream_t st);
 // dwf (+dwf_t): gradient w.r.t. the standardised weight, fp32, wf layout.
 // out: gradient w.r.t. raw weight (OIHW) and gain, written into gtheta at off_w / off_g
