@@ -244,13 +244,30 @@ __global__ void k_featgrad(LossWork w, float* __restrict__ xbar, float* __restri
   S hb[FG_MAX];
 #pragma unroll
   for (int q = 0; q < FG_MAX; ++q) hb[q] = mk<S>(0.f, 0.f);
-  for (int j = 0; j < n; ++j) {
-    size_t gi = isy ? (size_t)j * n + rr : (size_t)rr * n + j;
-    S gb = ldS<S>(w.Gb, w.Gb_t, gi);
+  // 4 rows of the other side per trip, all their loads issued before the FMAs (the accumulation is a
+  // loop-carried chain; one row per trip left every load waiting for the previous trip)
+  constexpr int JB = 4;
+  for (int j0 = 0; j0 < n; j0 += JB) {
+    S gb[JB];
+#pragma unroll
+    for (int jj = 0; jj < JB; ++jj) {
+      int j = j0 + jj;
+      size_t gi = isy ? (size_t)j * n + rr : (size_t)rr * n + j;
+      gb[jj] = j < n ? ldS<S>(w.Gb, w.Gb_t, gi) : mk<S>(0.f, 0.f);
+    }
 #pragma unroll
     for (int q = 0; q < FG_MAX; ++q) {
       int f = threadIdx.x + q * blockDim.x;
-      if (f < d) hb[q] = hb[q] + gb * ldS<S>(oth, oth_t, (size_t)j * d + f);
+      if (f < d) {
+        S o[JB];
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) {
+          int j = min(j0 + jj, n - 1);
+          o[jj] = ldS<S>(oth, oth_t, (size_t)j * d + f);
+        }
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) hb[q] = hb[q] + gb[jj] * o[jj];
+      }
     }
   }
   S dotp = mk<S>(0.f, 0.f);
