@@ -10,8 +10,9 @@
 //   the tangent pass computes  conv(a_dot, w_hat) + conv(a, w_hat_dot)  in one launch.
 //
 // Tiling: 256 threads = 4 waves (64 lanes).  Block tile BM x BN, K-step = one 128-byte row of K
-// (64 bf16 / 32 f32), LDS double-buffered, next tile's global loads issued before the MFMA
-// phase (register staging: the gather needs zero-fill at image borders).  LDS rows are 128 B =
+// (64 bf16 / 32 f32), ONE LDS stage: the next tile's global loads are issued into staging registers
+// before the MFMA phase and written to LDS after it (the gather needs zero-fill at image borders, and
+// 35 KB of LDS per block lets three blocks share a CU -- occupancy beats a second LDS stage here).  LDS rows are 128 B =
 // 8 chunks of 16 B; chunk position is XOR-swizzled with (row>>1)&7 so that every 16-lane group
 // of a ds_read_b128 hits 16 distinct 16-byte slots of the 256-byte bank row (conflict-free).
 // bf16: v_mfma_f32_32x32x16_bf16 ; f32 (parity mode): v_mfma_f32_32x32x2_f32 (exact fp32 FMA).
@@ -188,8 +189,8 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
     boff[i] = ((grp * G.nc + n) * ktot_w + (MODE == 2 ? 0 : cj * CE)) * ESZ;
   }
   // LDS byte addresses.  Rows 32 apart share the swizzle, so the i / j sub-tiles are reached with
-  // immediate offsets (i * 4096) from ONE register per q; the double buffer is toggled by XOR-ing
-  // one bit into these few registers per K-step (buffer strides are powers of two).
+  // immediate offsets (i * 4096) from ONE register per q.  (With MDD_SINGLE_BUF=0 a second LDS stage is
+  // toggled by XOR-ing one bit into these few registers per K-step: buffer strides are powers of two.)
   constexpr int ABUF = NBUF == 2 ? BM * 128 : 0, BBUF = NBUF == 2 ? BN * 128 : 0, BBASE = NBUF * BM * 128;
   const int l31 = lane & 31, lh = lane >> 5;
   int rdA[4], rdB[4];

@@ -12,7 +12,7 @@
 //         k-permutation (same for A and B); it is chosen so the two groups of a half-wave read
 //         rows 8x..8x+3 and 8x+4..8x+7, which with the XOR swizzle below is bank-conflict-free.
 // Output tile BCO x BKP (64x128 for group width 64, 128x128 otherwise), BKM pixels per barrier,
-// LDS double-buffered with the next tile's global loads in flight during the MFMA phase.
+// one LDS stage, the next tile's global loads in flight (staging registers) during the MFMA phase.
 // The M range is split across blockIdx.y and combined with fp32 atomics (dW is zeroed by the
 // caller).  An optional second pair (dy2, x2) is accumulated too (tangent pass), and the bias
 // gradient (column sums of dy1) is taken from the staging registers of the k'-tile-0 blocks.
