@@ -100,7 +100,9 @@ def main(args):
                 img = torch.randn(n, 3, args.image_size, args.image_size, device=device, generator=g)
                 txt = torch.randn(n, d_txt, device=device, generator=g) * 0.5253
                 x = eng.img_forward(0, th_i, img)
-                y = eng.txt_forward(0, th_t, txt)
+                # the text projection trains with Dropout(0.1) (networks.py:625-646, model.train())
+                mask = (torch.rand(n, eng.feature_dim, device=device, generator=g) >= 0.1).float() / 0.9
+                y = eng.txt_forward(0, th_t, txt, drop_mask=mask)
                 _, xb, yb, _ = eng.contrastive(x, y, 1.0 / 0.07)   # networks.py:878
                 gi = eng.img_backward(0, th_i, xb)
                 gt = eng.txt_backward(0, th_t, yb)

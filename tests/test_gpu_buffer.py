@@ -1,0 +1,82 @@
+"""GPU tests of the rows either side of the hot path: one first-order expert
+training step (reference buffer.py:73 -> epoch.py:59-98 -> networks.py:845-889: fixed logit scale
+1/0.07, SGD without momentum) against the CPU oracle, and the expert-buffer file format written by
+the stage-1 driver and read back by the stage-2 driver."""
+import os
+
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_expert_training_step_matches_oracle(report):
+    from multimodal_dataset_distillation_amd.engine import UnrollEngine
+    from oracle import distill_ref as dr
+    from test_gpu_engine import make_oracle
+    n, size, d_txt, lr = 6, 64, 32, 0.1
+    fi, ft = make_oracle("nfnet_tiny", d_txt, 11)
+    img, txt = dr.synthetic_inputs(n, size, d_txt, seed=3)
+    thi = fi.flat_param().clone().requires_grad_(True)
+    tht = ft.flat_param().clone().requires_grad_(True)
+    feat = ft.module.fc.out_features
+    mask = ((torch.rand(n, feat, generator=torch.Generator().manual_seed(4)) >= 0.1).float() / 0.9)
+    loss = dr.contrastive_loss(fi(img, flat_param=thi), ft(txt, flat_param=tht, drop_mask=mask), 1.0 / 0.07)
+    gi, gt = torch.autograd.grad(loss, [thi, tht])
+    ref_i, ref_t = (thi - lr * gi).detach(), (tht - lr * gt).detach()
+
+    dev = "cuda"
+    eng = UnrollEngine("nfnet_tiny", batch=n, num_queries=n, image_size=size, d_txt=d_txt, syn_steps=1,
+                       dtype="f32")
+    th_i, th_t = thi.detach().to(dev), tht.detach().to(dev)
+    x = eng.img_forward(0, th_i, img.to(dev))
+    y = eng.txt_forward(0, th_t, txt.to(dev), drop_mask=mask.to(dev))
+    l, xb, yb, _ = eng.contrastive(x, y, 1.0 / 0.07)
+    g_i = eng.img_backward(0, th_i, xb)
+    g_t = eng.txt_backward(0, th_t, yb)
+    new_i, new_t = th_i - lr * g_i, th_t - lr * g_t
+    torch.cuda.synchronize()
+    e = dict(loss=abs(l.item() - loss.item()) / abs(loss.item()),
+             g_img=rel_err(g_i.cpu(), gi), g_txt=rel_err(g_t.cpu(), gt),
+             th_img=rel_err(new_i.cpu(), ref_i), th_txt=rel_err(new_t.cpu(), ref_t))
+    report("expert training step (scale 1/0.07, dropout mask) vs oracle: "
+           + " ".join(f"{k} {float(v):.2e}" for k, v in e.items()))
+    assert all(float(v) < 1e-3 for v in e.values()), e
+    eng.close()
+
+
+def test_buffer_cli_writes_reference_format_and_distill_reads_it(report, tmp_path):
+    from multimodal_dataset_distillation_amd import buffer, distill, networks as nw
+    from multimodal_dataset_distillation_amd.engine import UnrollEngine
+    bdir = str(tmp_path / "buffers")
+    args = buffer.build_parser().parse_args(
+        ["--dataset", "flickr", "--num_experts", "2", "--train_epochs", "3", "--batch_train", "4",
+         "--image_size", "64", "--image_encoder", "nfnet_tiny", "--synthetic_data", "1",
+         "--compute_dtype", "f32", "--buffer_path", bdir])
+    buffer.main(args)
+    d = os.path.join(bdir, "flickr", "nfnet_tiny", "bert")
+    files = sorted(os.listdir(d))
+    assert files == ["img_replay_buffer_0.pt", "img_replay_buffer_1.pt", "txt_replay_buffer_0.pt",
+                     "txt_replay_buffer_1.pt"]
+    # the reference's nested-list layout (buffer.py:104-112), readable without unpickling code
+    traj = torch.load(os.path.join(d, "img_replay_buffer_0.pt"), map_location="cpu", weights_only=True)
+    assert len(traj) == 1 and len(traj[0]) == 4               # 1 expert per file, init + 3 epochs
+    eng = UnrollEngine("nfnet_tiny", batch=4, num_queries=4, image_size=64, d_txt=768, syn_steps=1,
+                       dtype="f32")
+    assert [tuple(t.shape) for t in traj[0][0]] == [tuple(s) for _, s, _ in eng.param_table("img")]
+    assert all(t.dtype == torch.float32 for t in traj[0][0])
+    moved = sum(float((a - b).abs().sum()) for a, b in zip(traj[0][0], traj[0][3]))
+    assert moved > 0                                           # the experts did train
+    eng.close()
+    # stage 2 consumes the directory exactly as the reference does (distill.py:255-283, 450-476)
+    a, _ = distill.build_parser().parse_known_args(
+        ["--image_encoder", "nfnet_tiny", "--num_queries", "4", "--mini_batch_size", "4", "--syn_steps", "2",
+         "--expert_epochs", "1", "--max_start_epoch", "2", "--Iteration", "3", "--image_size", "64",
+         "--lr_img", "0.5", "--lr_txt", "0.5", "--lr_lr", "1e-5", "--compute_dtype", "f32",
+         "--buffer_path", d, "--max_files", "2"])
+    img, txt, lr = distill.main(a)
+    assert torch.isfinite(img).all() and torch.isfinite(txt).all() and torch.isfinite(lr).all()
+    report(f"buffer.py -> {len(files)} files -> distill.py: |image_syn| {img.norm().item():.3f} lr {lr.tolist()}")
+    nw.release_engines()
