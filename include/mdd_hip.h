@@ -161,6 +161,19 @@ int mdd_op_conv2d_wgrad(int dtype, int nimg, int hin, int win, int cin, int cout
                         int pad, int groups, const void* dy_dev, const void* x_dev,
                         float* dw_packed_dev, float* dbias_dev, void* stream);
 
+/* ---- synthetic-set evaluation: retrieval ranks.
+ * Replaces the per-row host loops of reference epoch.py:140-156 (image->text: argsort of one similarity
+ * row, position of the best ground-truth caption), :163-192 (text->image) and itm_eval epoch.py:219-237.
+ * img_feat [n_img, dim], txt_feat [n_txt, dim]: un-normalised fp32 embeddings (normalised here as
+ * epoch.py:126/:148 do); scale = exp(log(1/0.07)) in the reference (epoch.py:106-107).
+ * img2txt: CSR lists of ground-truth caption ids per image (dataset.img2txt); txt2img[n_txt].
+ * scores_ws: n_img*n_txt floats, left holding the scaled similarity matrix; norm_ws: n_img+n_txt floats.
+ * rank_*: 0-based ranks = number of strictly better-scoring candidates.  All pointers device memory. */
+int mdd_retrieval_ranks(const float* img_feat, const float* txt_feat, const int* img2txt_off,
+                        const int* img2txt_idx, const int* txt2img, int n_img, int n_txt, int dim,
+                        float scale, float* scores_ws, float* norm_ws, int* rank_i2t, int* rank_t2i,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1104,4 +1104,17 @@ int mdd_op_conv2d_wgrad(int dtype, int nimg, int hin, int win, int cin, int cout
   return 0;
 }
 
+int mdd_retrieval_ranks(const float* img_feat, const float* txt_feat, const int* img2txt_off,
+                        const int* img2txt_idx, const int* txt2img, int n_img, int n_txt, int dim,
+                        float scale, float* scores_ws, float* norm_ws, int* rank_i2t, int* rank_t2i,
+                        void* stream) {
+  CHECK_ARG(img_feat && txt_feat && img2txt_off && img2txt_idx && txt2img, "null input pointer");
+  CHECK_ARG(scores_ws && norm_ws && rank_i2t && rank_t2i, "null output / workspace pointer");
+  CHECK_ARG(n_img > 0 && n_txt > 0 && dim > 0, "empty problem");
+  launch_retrieval_ranks(rank_i2t, rank_t2i, scores_ws, norm_ws, img_feat, txt_feat, img2txt_off,
+                         img2txt_idx, txt2img, n_img, n_txt, dim, scale, (hipStream_t)stream);
+  POST_LAUNCH("retrieval_ranks");
+  return 0;
+}
+
 }  // extern "C"

@@ -155,6 +155,14 @@ void launch_linear_wgrad(float* dW, float* db, const float* dy, const float* dy_
                          const float* x_t, int n, int k, int j, const LinScratch& ws,
                          hipStream_t st);
 
+// ---------------------------------------------------------------- retrieval.hip (fp32)
+// scores[b,n] = scale * <img_hat[i], txt_hat[j]> ; rank_i2t[i], rank_t2i[j] (see retrieval.hip).
+// img2txt as CSR (off[b+1], idx[]); rn_ws: b + n floats of scratch.
+void launch_retrieval_ranks(int* rank_i2t, int* rank_t2i, float* scores, float* rn_ws,
+                            const float* img_feat, const float* txt_feat, const int* img2txt_off,
+                            const int* img2txt_idx, const int* txt2img, int b, int n, int d,
+                            float scale, hipStream_t st);
+
 // ---------------------------------------------------------------- head.hip (fp32)
 void launch_gather_rows(float* out, const float* in, const int64_t* idx, int n, int d,
                         hipStream_t st);

@@ -1,0 +1,78 @@
+// Retrieval ranks of the synthetic-set evaluation (reference epoch.py:105-216 and
+// itm_eval :219-244): similarity of every test image with every test caption on L2-normalised
+// embeddings, then, per image, the rank of its best-ranked ground-truth caption and, per caption, the
+// rank of its ground-truth image.  The reference sorts one row at a time on the host
+// (np.argsort ... np.where); a rank is just a count, so here it is
+//     rank_i2t[i] = #{ j : s[i,j] > max_{c in gt(i)} s[i,c] }      rank_t2i[j] = #{ i : s[i,j] > s[gt(j),j] }
+// (ties count as not-greater; the reference's descending argsort leaves tie order unspecified).
+#include "kernels.h"
+
+namespace {
+
+// rn[r] = 1 / ||x[r,:]||_2
+__global__ void k_row_rnorm(float* __restrict__ rn, const float* __restrict__ x, int d) {
+  __shared__ float scratch[16];
+  const float* row = x + (size_t)blockIdx.x * d;
+  float s = 0.f;
+  for (int f = threadIdx.x; f < d; f += blockDim.x) s += row[f] * row[f];
+  s = block_sum(s, scratch);
+  if (threadIdx.x == 0) rn[blockIdx.x] = rsqrtf(s);
+}
+// s[i,j] *= scale * rni[i] * rnt[j]
+__global__ void k_scale_scores(float* __restrict__ s, const float* __restrict__ rni,
+                               const float* __restrict__ rnt, float scale, int b, int n) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)b * n;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int i = (int)(e / n), j = (int)(e - (int64_t)i * n);
+    s[e] *= scale * rni[i] * rnt[j];
+  }
+}
+// block per image
+__global__ void k_rank_i2t(int* __restrict__ rank, const float* __restrict__ s,
+                           const int* __restrict__ off, const int* __restrict__ idx, int n) {
+  __shared__ float scratch[16];
+  __shared__ float s_best;
+  const int i = blockIdx.x;
+  const float* row = s + (size_t)i * n;
+  if (threadIdx.x == 0) {
+    float best = -INFINITY;
+    for (int c = off[i]; c < off[i + 1]; ++c) best = fmaxf(best, row[idx[c]]);
+    s_best = best;
+  }
+  __syncthreads();
+  const float best = s_best;
+  float cnt = 0.f;
+  for (int j = threadIdx.x; j < n; j += blockDim.x) cnt += row[j] > best ? 1.f : 0.f;
+  cnt = block_sum(cnt, scratch);
+  if (threadIdx.x == 0) rank[i] = (int)cnt;
+}
+// block per caption (column of s)
+__global__ void k_rank_t2i(int* __restrict__ rank, const float* __restrict__ s,
+                           const int* __restrict__ txt2img, int b, int n) {
+  __shared__ float scratch[16];
+  const int j = blockIdx.x;
+  const float ref = s[(size_t)txt2img[j] * n + j];
+  float cnt = 0.f;
+  for (int i = threadIdx.x; i < b; i += blockDim.x) cnt += s[(size_t)i * n + j] > ref ? 1.f : 0.f;
+  cnt = block_sum(cnt, scratch);
+  if (threadIdx.x == 0) rank[j] = (int)cnt;
+}
+
+}  // namespace
+
+void launch_retrieval_ranks(int* rank_i2t, int* rank_t2i, float* scores, float* rn_ws,
+                            const float* img_feat, const float* txt_feat, const int* img2txt_off,
+                            const int* img2txt_idx, const int* txt2img, int b, int n, int d,
+                            float scale, hipStream_t st) {
+  float* rni = rn_ws;
+  float* rnt = rn_ws + b;
+  k_row_rnorm<<<b, 256, 0, st>>>(rni, img_feat, d);
+  k_row_rnorm<<<n, 256, 0, st>>>(rnt, txt_feat, d);
+  LinScratch none;   // >= 256 tiles at evaluation sizes; small cases run unsplit
+  launch_linear_fwd(scores, nullptr, img_feat, nullptr, txt_feat, nullptr, nullptr, nullptr, b, d, n, 0,
+                    none, st);
+  int grid = (int)std::min<int64_t>(((int64_t)b * n + 255) / 256, 4096);
+  k_scale_scores<<<grid, 256, 0, st>>>(scores, rni, rnt, scale, b, n);
+  k_rank_i2t<<<b, 256, 0, st>>>(rank_i2t, scores, img2txt_off, img2txt_idx, n);
+  k_rank_t2i<<<n, 256, 0, st>>>(rank_t2i, scores, txt2img, b, n);
+}

@@ -226,11 +226,45 @@ def gen_unroll(ReparamModule, RefHead, path, variant, n, size, d_txt, K, outer_i
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def gen_itm_eval(path):
+    """Retrieval metrics golden: inputs + the output of the REFERENCE's own itm_eval (epoch.py:219-244,
+    pure numpy), AST-extracted and executed on its own -- epoch.py as a module needs kornia/torchvision/
+    networks and cannot be imported."""
+    import contextlib
+    import io
+    src = open(os.path.join(REF, "epoch.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "itm_eval"][0]
+    ns = {"np": np, "torch": torch}      # the definition carries a @torch.no_grad() decorator
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "epoch.py:itm_eval", "exec"), ns)
+    ref_itm_eval = ns["itm_eval"]
+    from oracle import retrieval_ref as rr
+    rng = np.random.RandomState(7)
+    n_img, per, d = 24, 5, 48
+    n_txt = n_img * per
+    img2txt = [list(range(i * per, (i + 1) * per)) for i in range(n_img)]
+    txt2img = np.repeat(np.arange(n_img), per)
+    img = rng.randn(n_img, d).astype(np.float32)
+    txt = (0.22 * img[txt2img] + rng.randn(n_txt, d)).astype(np.float32)   # partly aligned: recalls in (0, 100)
+    sim = rr.similarity(img, txt)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref = ref_itm_eval(sim, sim.T.copy(), txt2img, img2txt)
+    mine = rr.itm_eval(sim, sim.T.copy(), txt2img, img2txt)
+    for k in ref:
+        assert abs(ref[k] - mine[k]) < 1e-9, (k, ref[k], mine[k])
+    r_i, r_t = rr.ranks(sim, sim.T.copy(), txt2img, img2txt)
+    np.savez(path, img_feat=img, txt_feat=txt, txt2img=txt2img.astype(np.int32),
+             img2txt=np.asarray(img2txt, dtype=np.int32), sim=sim, rank_i2t=r_i, rank_t2i=r_t,
+             keys=np.array(sorted(ref)), values=np.array([ref[k] for k in sorted(ref)], dtype=np.float64))
+    print("wrote", path, {k: round(v, 2) for k, v in ref.items()})
+
+
 def main():
     out = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out, exist_ok=True)
     ReparamModule, RefHead = load_reference_pieces()
-    which = sys.argv[1:] or ["text", "tiny", "c1"]
+    which = sys.argv[1:] or ["text", "tiny", "c1", "itm"]
+    if "itm" in which:
+        gen_itm_eval(os.path.join(out, "itm_eval_small.npz"))
     if "text" in which:
         gen_text_only(ReparamModule, RefHead, os.path.join(out, "text_only_unroll.npz"))
     if "tiny" in which:

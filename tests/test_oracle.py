@@ -126,3 +126,25 @@ def test_flat_module_matches_reference_reparam_module():
     th = torch.randn(fm.param_numel)
     x = torch.randn(5, 16)
     assert torch.allclose(fm(x, flat_param=th), rm(x, flat_param=th), atol=1e-6)
+
+
+def test_retrieval_oracle_matches_reference_itm_eval_golden():
+    """tests/golden/itm_eval_small.npz holds the output of the reference's own itm_eval
+    (epoch.py:219-244, executed by oracle/gen_golden.py) on the stored inputs."""
+    from oracle import retrieval_ref as rr
+    g = np.load(os.path.join(GOLDEN, "itm_eval_small.npz"))
+    sim = rr.similarity(g["img_feat"], g["txt_feat"])
+    assert np.allclose(sim, g["sim"], rtol=1e-6, atol=1e-6)
+    img2txt = [list(r) for r in g["img2txt"]]
+    res = rr.itm_eval(sim, sim.T.copy(), g["txt2img"], img2txt)
+    want = dict(zip([str(k) for k in g["keys"]], g["values"]))
+    assert set(res) == set(want)
+    for k in want:
+        assert abs(res[k] - want[k]) < 1e-9, (k, res[k], want[k])
+    r_i, r_t = rr.ranks(sim, sim.T.copy(), g["txt2img"], img2txt)
+    assert (r_i == g["rank_i2t"]).all() and (r_t == g["rank_t2i"]).all()
+    # the count form used on the GPU equals the argsort form when there are no ties
+    best = np.array([sim[i, img2txt[i]].max() for i in range(sim.shape[0])])
+    assert ((sim > best[:, None]).sum(1) == r_i).all()
+    ref = sim[g["txt2img"], np.arange(sim.shape[1])]
+    assert ((sim > ref[None, :]).sum(0) == r_t).all()
