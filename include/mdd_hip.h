@@ -174,6 +174,15 @@ int mdd_retrieval_ranks(const float* img_feat, const float* txt_feat, const int*
                         float scale, float* scores_ws, float* norm_ws, int* rank_i2t, int* rank_t2i,
                         void* stream);
 
+/* ---- caption decode of the synthetic text embeddings: for every query row the index
+ * of the most cosine-similar bank row.  Replaces reference distill.py:89-95 (`nearest_neighbor`: one
+ * sklearn cosine_similarity + np.argmax per query against all ~145k train caption embeddings), called at
+ * distill.py:244 and :374.  Ties resolve to the lowest index (np.argmax).
+ * query [n_query, dim], bank [n_bank, dim] fp32; scores_ws n_query*n_bank floats (left holding the cosine
+ * matrix); norm_ws n_query+n_bank floats; idx_out [n_query].  All device memory. */
+int mdd_nearest_neighbor(const float* query, const float* bank, int n_query, int n_bank, int dim,
+                         float* scores_ws, float* norm_ws, int* idx_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1117,4 +1117,13 @@ int mdd_retrieval_ranks(const float* img_feat, const float* txt_feat, const int*
   return 0;
 }
 
+int mdd_nearest_neighbor(const float* query, const float* bank, int n_query, int n_bank, int dim,
+                         float* scores_ws, float* norm_ws, int* idx_out, void* stream) {
+  CHECK_ARG(query && bank && scores_ws && norm_ws && idx_out, "null pointer");
+  CHECK_ARG(n_query > 0 && n_bank > 0 && dim > 0, "empty problem");
+  launch_nearest_neighbor(idx_out, scores_ws, norm_ws, query, bank, n_query, n_bank, dim, (hipStream_t)stream);
+  POST_LAUNCH("nearest_neighbor");
+  return 0;
+}
+
 }  // extern "C"

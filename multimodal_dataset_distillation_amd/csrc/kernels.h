@@ -163,6 +163,10 @@ void launch_retrieval_ranks(int* rank_i2t, int* rank_t2i, float* scores, float* 
                             const int* img2txt_idx, const int* txt2img, int b, int n, int d,
                             float scale, hipStream_t st);
 
+// idx_out[i] = argmax_j cos(query[i], bank[j]) (first maximum); scores [q,n] and rn_ws [q+n] scratch
+void launch_nearest_neighbor(int* idx_out, float* scores, float* rn_ws, const float* query,
+                             const float* bank, int q, int n, int d, hipStream_t st);
+
 // ---------------------------------------------------------------- head.hip (fp32)
 void launch_gather_rows(float* out, const float* in, const int64_t* idx, int n, int d,
                         hipStream_t st);

@@ -58,7 +58,46 @@ __global__ void k_rank_t2i(int* __restrict__ rank, const float* __restrict__ s,
   if (threadIdx.x == 0) rank[j] = (int)cnt;
 }
 
+// block per query row: first index of the row maximum (np.argmax semantics on ties)
+__global__ void k_row_argmax(int* __restrict__ out, const float* __restrict__ s, int n) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  const float* row = s + (size_t)blockIdx.x * n;
+  float best = -INFINITY;
+  int bi = n;
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    float v = row[j];
+    if (v > best) { best = v; bi = j; }          // strided scan: the first hit per thread is its lowest index
+  }
+  sv[threadIdx.x] = best; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      float v = sv[threadIdx.x + o];
+      int i = si[threadIdx.x + o];
+      if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && i < si[threadIdx.x])) {
+        sv[threadIdx.x] = v; si[threadIdx.x] = i;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = si[0];
+}
+
 }  // namespace
+
+void launch_nearest_neighbor(int* idx_out, float* scores, float* rn_ws, const float* query,
+                             const float* bank, int q, int n, int d, hipStream_t st) {
+  float* rnq = rn_ws;
+  float* rnb = rn_ws + q;
+  k_row_rnorm<<<q, 256, 0, st>>>(rnq, query, d);
+  k_row_rnorm<<<n, 256, 0, st>>>(rnb, bank, d);
+  LinScratch none;
+  launch_linear_fwd(scores, nullptr, query, nullptr, bank, nullptr, nullptr, nullptr, q, d, n, 0, none, st);
+  int grid = (int)std::min<int64_t>(((int64_t)q * n + 255) / 256, 4096);
+  k_scale_scores<<<grid, 256, 0, st>>>(scores, rnq, rnb, 1.f, q, n);
+  k_row_argmax<<<q, 256, 0, st>>>(idx_out, scores, n);
+}
 
 void launch_retrieval_ranks(int* rank_i2t, int* rank_t2i, float* scores, float* rn_ws,
                             const float* img_feat, const float* txt_feat, const int* img2txt_off,

@@ -107,6 +107,31 @@ def build_parser():
     return p
 
 
+def nearest_neighbor(sentences, query_embeddings, database_embeddings, device="cuda", return_index=False):
+    """reference distill.py:89-95 (decode of `text_syn` at :244 / :374): for each query embedding the
+    sentence whose embedding is most cosine-similar.  One `mdd_nearest_neighbor` launch chain on the GPU
+    (norms, [Q x N] cosine GEMM, row argmax) instead of Q sklearn calls over the whole bank."""
+    from . import _lib
+    lib = _lib.load()
+    q = torch.as_tensor(np.asarray(query_embeddings) if not torch.is_tensor(query_embeddings) else query_embeddings)
+    b = torch.as_tensor(np.asarray(database_embeddings) if not torch.is_tensor(database_embeddings) else database_embeddings)
+    q, b = q.detach().float().to(device).contiguous(), b.detach().float().to(device).contiguous()
+    if q.dim() != 2 or b.dim() != 2 or q.shape[1] != b.shape[1]:
+        raise ValueError("nearest_neighbor: [Q,D] queries and [N,D] database expected")
+    if sentences is not None and len(sentences) != b.shape[0]:
+        raise ValueError("nearest_neighbor: one sentence per database row expected")
+    scores = torch.empty(q.shape[0], b.shape[0], device=device)
+    norms = torch.empty(q.shape[0] + b.shape[0], device=device)
+    idx = torch.empty(q.shape[0], dtype=torch.int32, device=device)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(lib.mdd_nearest_neighbor(P(q), P(b), q.shape[0], b.shape[0], q.shape[1], P(scores), P(norms),
+                                        P(idx), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    ids = idx.cpu().tolist()
+    if return_index:
+        return ids
+    return [sentences[i] for i in ids]
+
+
 def init_synthetic_set(args, d_txt, device):
     """upstream noise init (distill_original.py:138-148)."""
     if args.pix_init != "noise" or args.txt_init != "noise":

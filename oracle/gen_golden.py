@@ -258,11 +258,35 @@ def gen_itm_eval(path):
     print("wrote", path, {k: round(v, 2) for k, v in ref.items()})
 
 
+def gen_nearest_neighbor(path):
+    """Caption-decode golden: the reference's own nearest_neighbor (distill.py:89-95, AST-extracted; it
+    needs only numpy + sklearn's cosine_similarity, which is installed here) on a small bank."""
+    from sklearn.metrics.pairwise import cosine_similarity
+    src = open(os.path.join(REF, "distill.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "nearest_neighbor"][0]
+    ns = {"np": np, "cosine_similarity": cosine_similarity}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "distill.py:nearest_neighbor", "exec"), ns)
+    rng = np.random.RandomState(11)
+    n, q, d = 400, 16, 64
+    bank = rng.randn(n, d).astype(np.float32)
+    pick = rng.permutation(n)[:q]
+    query = (bank[pick] * rng.uniform(0.5, 2.0, size=(q, 1)) + 2.2 * rng.randn(q, d)).astype(np.float32)
+    sentences = ["caption %d" % i for i in range(n)]
+    got = ns["nearest_neighbor"](sentences, query, bank)
+    from oracle import retrieval_ref as rr
+    assert got == rr.nearest_neighbor(sentences, query, bank)
+    idx = np.array([int(s.split()[1]) for s in got], dtype=np.int32)
+    np.savez(path, bank=bank, query=query, index=idx)
+    print("wrote", path, "hits on the planted rows:", int((idx == pick).sum()), "of", q)
+
+
 def main():
     out = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out, exist_ok=True)
     ReparamModule, RefHead = load_reference_pieces()
-    which = sys.argv[1:] or ["text", "tiny", "c1", "itm"]
+    which = sys.argv[1:] or ["text", "tiny", "c1", "itm", "nn"]
+    if "nn" in which:
+        gen_nearest_neighbor(os.path.join(out, "nearest_neighbor_small.npz"))
     if "itm" in which:
         gen_itm_eval(os.path.join(out, "itm_eval_small.npz"))
     if "text" in which:

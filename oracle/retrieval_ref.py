@@ -39,3 +39,16 @@ def recalls(r_i, r_t):
 
 def itm_eval(scores_i2t, scores_t2i, txt2img, img2txt):
     return recalls(*ranks(scores_i2t, scores_t2i, txt2img, img2txt))
+
+
+def nearest_neighbor(sentences, query_embeddings, database_embeddings):
+    """reference distill.py:89-95, with sklearn's cosine_similarity written out
+    (x.y / (|x||y|), sklearn.metrics.pairwise.cosine_similarity) and np.argmax (first maximum)."""
+    q = np.asarray(query_embeddings, dtype=np.float64)
+    b = np.asarray(database_embeddings, dtype=np.float64)
+    qn = q / np.linalg.norm(q, axis=1, keepdims=True)
+    bn = b / np.linalg.norm(b, axis=1, keepdims=True)
+    out = []
+    for row in qn:
+        out.append(sentences[int(np.argmax(bn @ row))])
+    return out

@@ -148,3 +148,19 @@ def test_retrieval_oracle_matches_reference_itm_eval_golden():
     assert ((sim > best[:, None]).sum(1) == r_i).all()
     ref = sim[g["txt2img"], np.arange(sim.shape[1])]
     assert ((sim > ref[None, :]).sum(0) == r_t).all()
+
+
+def test_nearest_neighbor_oracle_matches_reference_golden_and_sklearn():
+    """tests/golden/nearest_neighbor_small.npz holds the output of the reference's own nearest_neighbor
+    (distill.py:89-95).  sklearn (the reference's dependency) is importable here, so the restatement is
+    also checked against cosine_similarity directly."""
+    from oracle import retrieval_ref as rr
+    g = np.load(os.path.join(GOLDEN, "nearest_neighbor_small.npz"))
+    sentences = list(range(g["bank"].shape[0]))
+    got = rr.nearest_neighbor(sentences, g["query"], g["bank"])
+    assert got == g["index"].tolist()
+    from sklearn.metrics.pairwise import cosine_similarity
+    rng = np.random.RandomState(0)
+    bank, query = rng.randn(300, 40), rng.randn(9, 40)
+    want = [int(np.argmax(cosine_similarity(q.reshape(1, -1), bank))) for q in query]
+    assert rr.nearest_neighbor(list(range(300)), query, bank) == want
