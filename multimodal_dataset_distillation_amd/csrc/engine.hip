@@ -435,6 +435,12 @@ struct Eng : mdd_engine {
   // they run beside the data-gradient chain instead of in it (both are latency-bound on their own).
   hipStream_t side = nullptr;
   bool use_side = true;
+  ~Eng() override {   // streams / events created at bind(); the workspace belongs to the caller
+    if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+    if (tside) { (void)hipStreamSynchronize(tside); (void)hipStreamDestroy(tside); }
+    for (auto e : evs) (void)hipEventDestroy(e);
+    for (auto& p : prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  }
   std::vector<hipEvent_t> evs;
   size_t evi = 0;
   hipEvent_t next_event() {
