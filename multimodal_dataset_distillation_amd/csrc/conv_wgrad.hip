@@ -37,14 +37,13 @@ struct WArgs {
   int M, cotiles, kptiles, mchunk, dbg;
 };
 
+typedef unsigned __attribute__((ext_vector_type(4))) u32x4;   // first-class 16-byte register value
+
 // LDS chunk swizzle (bf16 path only): rows of ROWB bytes
-DEVI uint4 mask4(uint4 v, bool keep) {
-  unsigned m = keep ? 0xffffffffu : 0u;
-  return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
-}
 template <int ROWB> DEVI int wswz(int row) { return ROWB == 128 ? ((row >> 1) & 3) : (row & 7); }
 
-template <class AT, int BCO, int BKP, int BKM>
+// PW: pointwise (1x1, stride 1, no padding) instance -- no gather state, no per-step pixel decode
+template <class AT, int BCO, int BKP, int BKM, bool PW>
 __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArgs p) {
   constexpr int CE = 16 / (int)sizeof(AT);
   constexpr bool BF = sizeof(AT) == 2;
@@ -86,7 +85,12 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
   const int niter1 = mend > mbeg ? (mend - mbeg + BKM - 1) / BKM : 0;
   const int niter = (p.dbg & 1) ? (niter1 > 0 ? 1 : 0) : (p.dy2 ? 2 * niter1 : niter1);   // dbg bit0: timing only
 
-  // ---- staging geometry.  dy: chunk col dcol, rows drow + DSTEP*i ; x: xcol, rows xrow + XSTEP*i
+  // ---- staging geometry.  dy: chunk col dcol, rows drow + DSTEP*i ; x: xcol, rows xrow + XSTEP*i.
+  // All global loads are BUFFER loads: a wave-uniform descriptor + a 32-bit per-lane byte offset that is
+  // fixed for the whole launch + a scalar offset that advances BKM pixels per step.  Elements that must
+  // read as zero (rows past the M chunk, taps outside the image, K / channel tails) get an
+  // out-of-range offset -- the hardware returns 0 -- so a load costs one compare + one select instead
+  // of 64-bit address arithmetic and a mask (this loop is instruction-issue bound).
   const int dcol = tid % DCH, drow = tid / DCH;
   const int xcol = tid % XCH, xrow = tid / XCH;
   // x chunk -> (tap, kc) is iteration-invariant
@@ -95,12 +99,32 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
   const int tap = kp / G.kc, kcq = kp - tap * G.kc;
   const int ty = tap / G.k, tx = tap - ty * G.k;
   const bool dco_ok = (co0 + dcol * CE) < G.nc;
-  const bool pointwise = G.k == 1 && G.stride == 1 && G.pad == 0;
-  const AT* dyb = nullptr;
-  const size_t dy_col = (size_t)grp * G.nc + co0 + dcol * CE;
-  const size_t x_col = (size_t)grp * G.kc + kcq;
+  constexpr bool pointwise = PW;
+  // source pixel index is (output pixel index + constant) for stride-1 "same" convolutions
+  const bool lin = pointwise || (G.stride == 1 && G.ha == G.ho && G.wa == G.wo);
+  constexpr int ESZ = (int)sizeof(AT);
+  constexpr unsigned OOB = 0x80000000u;
+  const int margin = lin ? G.pad * G.wa + G.pad : 0;          // keeps every per-lane offset >= 0
+  auto rsrc = [&](const void* base, int64_t elem_off) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + elem_off * ESZ), (short)0, 0x7fffffff,
+                                             0x00020000);
+  };
+  const int64_t dy_base = (int64_t)mbeg * G.co_tot + (int64_t)grp * G.nc + co0;
+  const int64_t x_base = lin ? ((int64_t)mbeg - margin) * G.ca_tot + (int64_t)grp * G.kc : (int64_t)grp * G.kc;
+  const __amdgpu_buffer_rsrc_t rs_dy1 = rsrc(p.dy1, dy_base), rs_x1 = rsrc(p.x1, x_base);
+  const __amdgpu_buffer_rsrc_t rs_dy2 = rsrc(p.dy2 ? p.dy2 : p.dy1, dy_base), rs_x2 = rsrc(p.x2 ? p.x2 : p.x1, x_base);
+  unsigned dvo[DSL], xvo[XSL];
+#pragma unroll
+  for (int i = 0; i < DSL; ++i)
+    dvo[i] = dco_ok ? (unsigned)(((drow + DSTEP * i) * G.co_tot + dcol * CE) * ESZ) : OOB;
+#pragma unroll
+  for (int i = 0; i < XSL; ++i) {
+    int shift = lin ? margin + (ty - G.pad) * G.wa + (tx - G.pad) : 0;
+    xvo[i] = kp_ok ? (unsigned)(((xrow + XSTEP * i + shift) * G.ca_tot + kcq) * ESZ) : OOB;
+  }
+  const int dstep = BKM * G.co_tot * ESZ, xstep = BKM * G.ca_tot * ESZ;   // bytes per K-step
 
-  // running (image, oy, ox) of each x row slot; advanced by BKM pixels per iteration
+  // running (image, oy, ox) of each x row slot (gathered convs only); advanced by BKM pixels per iteration
   int sox[XSL], soy[XSL], sni[XSL];
   auto init_rows = [&]() {
 #pragma unroll
@@ -112,10 +136,10 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
       sni[i] = t / G.ho;
     }
   };
-  if (!pointwise) init_rows();
+  if constexpr (!pointwise) init_rows();
 
-  uint4 rd[DSL], rx[XSL];
-  bool okD[DSL], okX[XSL], bias_now = false;   // zero-select deferred to the LDS store
+  u32x4 rd[DSL], rx[XSL];
+  bool bias_now = false;
   float bsum[CE];
 #pragma unroll
   for (int e = 0; e < CE; ++e) bsum[e] = 0.f;
@@ -123,33 +147,34 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
 
   auto load_tile = [&](int it) {
     const bool second = it >= niter1;
-    const AT* DY = (const AT*)(second ? p.dy2 : p.dy1);
-    const AT* X = (const AT*)(second ? p.x2 : p.x1);
-    if (it == niter1 && !pointwise) init_rows();
-    const int mb = mbeg + (second ? it - niter1 : it) * BKM;
+    if constexpr (!pointwise) { if (it == niter1) init_rows(); }
+    const int itl = second ? it - niter1 : it;
+    const int rem = mend - mbeg - itl * BKM;          // rows of this chunk still ahead (uniform)
+    const __amdgpu_buffer_rsrc_t rd_ = second ? rs_dy2 : rs_dy1;
+    const __amdgpu_buffer_rsrc_t rx_ = second ? rs_x2 : rs_x1;
 #pragma unroll
     for (int i = 0; i < DSL; ++i) {
-      int m = mb + drow + DSTEP * i;
-      bool ok = m < mend && dco_ok;
-      okD[i] = ok;
-      rd[i] = *(const uint4*)(DY + (ok ? (size_t)m * G.co_tot + dy_col : 0));
+      unsigned vo = (drow + DSTEP * i) < rem ? dvo[i] : OOB;
+      rd[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rd_, (int)vo, itl * dstep, 0));
     }
 #pragma unroll
     for (int i = 0; i < XSL; ++i) {
-      int m = mb + xrow + XSTEP * i;
-      bool ok = kp_ok && m < mend;
-      size_t pix = (size_t)m;
-      if (!pointwise) {
+      bool ok = (xrow + XSTEP * i) < rem;
+      unsigned vo = xvo[i];
+      int so = itl * xstep;
+      if constexpr (!pointwise) {
         int iy = soy[i] * G.stride - G.pad + ty, ix = sox[i] * G.stride - G.pad + tx;
         ok = ok && (unsigned)iy < (unsigned)G.ha && (unsigned)ix < (unsigned)G.wa;
-        pix = (size_t)(sni[i] * G.ha + iy) * G.wa + ix;
+        if (!lin) {   // strided: the source pixel is not linear in m -- absolute offset, no scalar advance
+          vo = kp_ok ? (unsigned)((((sni[i] * G.ha + iy) * G.wa + ix) * G.ca_tot + kcq) * ESZ) : OOB;
+          so = 0;
+        }
         // advance this slot to the next iteration's pixel
         sox[i] += BKM;
         while (sox[i] >= G.wo) { sox[i] -= G.wo; ++soy[i]; }
         while (soy[i] >= G.ho) { soy[i] -= G.ho; ++sni[i]; }
       }
-      okX[i] = ok;
-      rx[i] = *(const uint4*)(X + (ok ? pix * G.ca_tot + x_col : 0));
+      rx[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx_, (int)(ok ? vo : OOB), so, 0));
     }
     bias_now = do_bias && !second;
   };
@@ -160,11 +185,10 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
     for (int i = 0; i < DSL; ++i) {
       int r = drow + DSTEP * i;
       int c = BF ? (dcol ^ (wswz<DROWB>(r) << 1)) : dcol;
-      uint4 v = mask4(rd[i], okD[i]);
-      *(uint4*)(d + r * DROWB + c * 16) = v;
+      *(u32x4*)(d + r * DROWB + c * 16) = rd[i];
       if (bias_now) {
         float f[CE];
-        Chunk<AT>::unpack(v, f);
+        Chunk<AT>::unpack(__builtin_bit_cast(uint4, rd[i]), f);
 #pragma unroll
         for (int e = 0; e < CE; ++e) bsum[e] += f[e];
       }
@@ -173,7 +197,7 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
     for (int i = 0; i < XSL; ++i) {
       int r = xrow + XSTEP * i;
       int c = BF ? (xcol ^ (wswz<XROWB>(r) << 1)) : xcol;
-      *(uint4*)(x + r * XROWB + c * 16) = mask4(rx[i], okX[i]);
+      *(u32x4*)(x + r * XROWB + c * 16) = rx[i];
     }
   };
 
@@ -301,11 +325,11 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
       if (co0 + tid < G.nc) atomicAdd(p.dbias + grp * G.nc + co0 + tid, s);
     }
   }
-  (void)dyb;
 }
 
 template <class AT, int BCO, int BKP, int BKM>
 void launch_cfg(WArgs a, hipStream_t st) {
+  const bool pw = a.g.k == 1 && a.g.stride == 1 && a.g.pad == 0;
   const ConvGeom& g = a.g;
   int ktot = g.k * g.k * g.kc;
   a.cotiles = (g.nc + BCO - 1) / BCO;
@@ -338,7 +362,8 @@ void launch_cfg(WArgs a, hipStream_t st) {
   static const int dbg = [] { const char* e = getenv("MDD_DBG"); return e ? atoi(e) : 0; }();
   a.dbg = dbg;
   dim3 grid(tiles, splits);
-  k_conv_wgrad<AT, BCO, BKP, BKM><<<grid, 256, 0, st>>>(a);
+  if (pw) k_conv_wgrad<AT, BCO, BKP, BKM, true><<<grid, 256, 0, st>>>(a);
+  else k_conv_wgrad<AT, BCO, BKP, BKM, false><<<grid, 256, 0, st>>>(a);
 }
 
 }  // namespace
