@@ -78,3 +78,28 @@ def test_c2_workspace_fits_hbm():
     print("C2 workspace GiB:", gib)
     assert gib < 240
     eng.close()
+
+
+def test_param_tables_of_every_variant_match_the_oracle_flatten_order():
+    """Spec-only engines (no GPU call): the C-ABI parameter table (name, shape, offset) of every
+    supported topology equals the oracle's ReparamModule-order flattening (reparam_module.py:28-39)."""
+    import numpy as np
+    import torch
+    from multimodal_dataset_distillation_amd.engine import UnrollEngine
+    from oracle import distill_ref as dr, nfnet_ref as nr
+    for variant, size in (("nfnet_l0", 224), ("nfnet_l1", 224), ("nfnet_tiny", 64)):
+        eng = UnrollEngine(variant, batch=4, image_size=size, d_txt=768, syn_steps=1, dtype="bf16", bind=False)
+        torch.manual_seed(0)
+        enc = nr.ImageEncoder(variant)
+        fi = dr.FlatModule(enc)
+        ft = dr.FlatModule(dr.ProjectionHead(768, enc.model.num_features))
+        for tab, fm in ((eng.param_table("img"), fi), (eng.param_table("txt"), ft)):
+            assert [t[0] for t in tab] == fm.names
+            assert [tuple(t[1]) for t in tab] == [tuple(s) for s in fm.shapes]
+            assert [t[2] for t in tab] == np.cumsum([0] + fm.numels[:-1]).tolist()
+        assert eng.feature_dim == enc.model.num_features
+        eng.close()
+    # anchors: timm's published nfnet_l0 size minus its 1000-way head (SURVEY 8a5)
+    e0 = UnrollEngine("nfnet_l0", batch=4, bind=False)
+    assert e0.P_img == 32769488 and e0.P_img + 2304 * 1000 + 1000 == 35074488 and e0.P_txt == 7087104
+    e0.close()

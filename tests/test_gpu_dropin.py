@@ -156,3 +156,25 @@ def test_distill_cli_runs(engine, report, tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), "distilled_roco.pt"))
     report(f"distill CLI ({engine}): |image_syn| {img.norm().item():.4f} |text_syn| {txt.norm().item():.4f} lr {lr.tolist()}")
     nw.release_engines()
+
+
+def test_distill_cli_breaks_on_nan_like_the_reference(capsys, tmp_path, monkeypatch):
+    """reference distill.py:599-600: a NaN parameter loss ends the outer loop; nothing is stepped with NaNs."""
+    from multimodal_dataset_distillation_amd import distill, expert_buffer, networks as nw
+    real = expert_buffer.synthetic_buffer
+
+    def poisoned(*a, **kw):
+        buf = real(*a, **kw)
+        buf.img[:, 1:, :7] = float("nan")          # every target snapshot carries NaNs
+        return buf
+    monkeypatch.setattr(expert_buffer, "synthetic_buffer", poisoned)
+    args, _ = distill.build_parser().parse_known_args(
+        ["--image_encoder", "nfnet_tiny", "--num_queries", "4", "--mini_batch_size", "4", "--syn_steps", "1",
+         "--expert_epochs", "1", "--max_start_epoch", "1", "--Iteration", "5", "--image_size", "64",
+         "--synthetic_experts", "2", "3", "--compute_dtype", "f32"])
+    torch.manual_seed(0)
+    img, txt, lr = distill.main(args)
+    out = capsys.readouterr().out
+    assert "NaN" in out and "iteration 0" in out
+    assert torch.isfinite(img).all() and torch.isfinite(txt).all() and torch.isfinite(lr).all()
+    nw.release_engines()

@@ -256,3 +256,51 @@ def test_unrolled_match_golden_tiny(dtype, report):
         image_syn.copy_(T(f"it{it}_image_syn_after"))
         text_syn.copy_(T(f"it{it}_text_syn_after"))
         lr.copy_(T(f"it{it}_lr_after"))
+
+
+def test_unrolled_match_minibatch_subset_dropout_and_fixed_scale(report):
+    """Edge cases of the loop the goldens do not exercise: mini_batch_size < num_queries (index subsets
+    that overlap between steps, so image/text gradients of one row accumulate over steps -- reference
+    distill.py:510-513), student dropout masks (distill.py:446-447 puts the text projection in train
+    mode) and the upstream constant logit scale (distill_original.py:430).  f32 mode vs the oracle."""
+    from multimodal_dataset_distillation_amd.engine import UnrollEngine
+    from oracle import distill_ref as dr
+    nq, batch, size, d_txt, K = 7, 4, 64, 32, 3
+    fi, ft = make_oracle("nfnet_tiny", d_txt, 21)
+    feat = ft.module.fc.out_features
+    img, txt = dr.synthetic_inputs(nq, size, d_txt, seed=9)
+    g = torch.Generator().manual_seed(5)
+    perms = [torch.randperm(nq, generator=g)[:batch] for _ in range(K)]
+    masks = [(torch.rand(batch, feat, generator=g) >= 0.1).float() / 0.9 for _ in range(K)]
+    th0i, th0t = fi.flat_param(), ft.flat_param()
+    tgi = th0i + 2e-3 * torch.randn(th0i.shape, generator=g)
+    tgt = th0t + 2e-3 * torch.randn(th0t.shape, generator=g)
+    dev = "cuda"
+    for scale in (None, 1.0 / 0.07):
+        im, tx = img.clone().requires_grad_(True), txt.clone().requires_grad_(True)
+        lri = torch.tensor(0.1, requires_grad=True); lrt = torch.tensor(0.05, requires_grad=True)
+        grand, info = dr.unrolled_match(fi, ft, im, tx, lri, lrt, th0i, th0t, tgi, tgt, perms,
+                                        drop_masks=masks, logit_scale=scale)
+        if scale is None:
+            gi, gt_, gli, glt = dr.outer_grads(grand, im, tx, lri, lrt)
+        else:   # a constant scale takes syn_lr_img out of the logits: its gradient comes from the updates only
+            gi, gt_, gli, glt = torch.autograd.grad(grand, [im, tx, lri, lrt])
+        eng = UnrollEngine("nfnet_tiny", batch=batch, num_queries=nq, image_size=size, d_txt=d_txt,
+                           syn_steps=K, dtype="f32")
+        lr = torch.tensor([0.1, 0.05], device=dev)
+        out = eng.unrolled_match(img.to(dev), txt.to(dev), lr[0:1], lr[1:2], th0i.to(dev), th0t.to(dev),
+                                 tgi.to(dev), tgt.to(dev), perms=torch.stack(perms).to(dev),
+                                 drop_masks=torch.stack(masks).to(dev), logit_scale=scale)
+        torch.cuda.synchronize()
+        e = dict(grand=abs(out["grand_loss"].item() - grand.item()) / abs(grand.item()),
+                 ces=rel_err(out["contrastive"], torch.stack(info["contrastive"])),
+                 g_img=rel_err(out["image_syn"], gi), g_txt=rel_err(out["text_syn"], gt_),
+                 g_lri=abs(out["lr"][0].item() - gli.item()) / abs(gli.item()),
+                 g_lrt=abs(out["lr"][1].item() - glt.item()) / abs(glt.item()))
+        # rows never drawn by any step must have exactly zero gradient
+        used = torch.zeros(nq, dtype=torch.bool); used[torch.cat(perms)] = True
+        assert (out["image_syn"].cpu()[~used] == 0).all() and (out["text_syn"].cpu()[~used] == 0).all()
+        report(f"unrolled_match subset batch {batch}/{nq}, dropout, scale={'lr_img' if scale is None else '1/0.07'}: "
+               + " ".join(f"{k} {float(v):.2e}" for k, v in e.items()))
+        assert all(float(v) < 1e-3 for v in e.values()), e
+        eng.close()
