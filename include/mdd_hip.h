@@ -115,6 +115,15 @@ int mdd_contrastive_tangent(mdd_engine* e, const float* x_dev, const float* y_de
                             float scale_const, float* xbar_dot_dev, float* ybar_dot_dev,
                             float* sbar_dot_dev, void* stream);
 
+/* The same head without an engine, for any row count: sample-sharded runs (SURVEY 8e mode B, what
+ * `--distributed` / nn.DataParallel does at distill.py:443-445, 515-517) evaluate it on the all-gathered
+ * [n, d] features of every rank.  x_dot/y_dot NULL: loss, xbar, ybar, sbar; non-NULL: their directional
+ * derivatives into the same output pointers (loss unused).  work: mdd_op_contrastive_workspace_floats(n, d). */
+int64_t mdd_op_contrastive_workspace_floats(int n, int d);
+int mdd_op_contrastive(int n, int d, const float* x_dev, const float* y_dev, const float* x_dot_dev,
+                       const float* y_dot_dev, const float* scale_dev, float scale_const, float* work_dev,
+                       float* loss_dev, float* xbar_dev, float* ybar_dev, float* sbar_dev, void* stream);
+
 /* ---- flat fp32 parameter streams */
 int mdd_flat_axpy(float* out_dev, const float* x_dev, const float* g_dev, const float* lr_dev,
                   float sign, int64_t n, void* stream);       /* out = x + sign*lr*g */

@@ -63,6 +63,8 @@ SIGNATURES = {
     "mdd_unrolled_match": (_I, [_P, C.POINTER(MddIterArgs), _P]),
     "mdd_op_conv2d": (_I, [_I] * 11 + [_P, _P, _P, _P, _P]),
     "mdd_op_conv2d_wgrad": (_I, [_I] * 10 + [_P, _P, _P, _P, _P]),
+    "mdd_op_contrastive_workspace_floats": (_L, [_I, _I]),
+    "mdd_op_contrastive": (_I, [_I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P]),
     "mdd_retrieval_ranks": (_I, [_P] * 5 + [_I] * 3 + [C.c_float] + [_P] * 5),
     "mdd_nearest_neighbor": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
 }

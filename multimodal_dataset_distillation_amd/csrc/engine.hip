@@ -1027,6 +1027,21 @@ int mdd_contrastive_tangent(mdd_engine* e, const float* x, const float* y, const
   return e->contrastive(true, x, y, xd, yd, scale_dev, scale_const, nullptr, xbd, ybd, sbd,
                         (hipStream_t)stream);
 }
+int64_t mdd_op_contrastive_workspace_floats(int n, int d) { return loss_work_floats(n, d); }
+int mdd_op_contrastive(int n, int d, const float* x, const float* y, const float* xd, const float* yd,
+                       const float* scale_dev, float scale_const, float* work, float* loss, float* xbar,
+                       float* ybar, float* sbar, void* stream) {
+  CHECK_ARG(n > 0 && d > 0 && x && y && work && xbar && ybar && sbar, "null pointer / empty problem");
+  CHECK_ARG((xd == nullptr) == (yd == nullptr), "x_dot and y_dot come together");
+  CHECK_ARG(xd || loss, "loss output is null");
+  LossWork w = loss_work_carve(work, n, d);
+  if (!xd) launch_contrastive(w, loss, xbar, ybar, sbar, nullptr, nullptr, nullptr, x, y, nullptr, nullptr,
+                              scale_dev, scale_const, n, d, (hipStream_t)stream);
+  else launch_contrastive(w, nullptr, nullptr, nullptr, nullptr, xbar, ybar, sbar, x, y, xd, yd, scale_dev,
+                          scale_const, n, d, (hipStream_t)stream);
+  POST_LAUNCH("op_contrastive");
+  return 0;
+}
 int mdd_flat_axpy(float* out, const float* x, const float* g, const float* lr, float sign,
                   int64_t n, void* stream) {
   CHECK_ARG(out && x && g && lr && n >= 0, "null pointer");

@@ -190,14 +190,23 @@ def main(args):
     torch.cuda.set_device(device)
     args.device = str(device)
     torch.manual_seed(args.seed)
-    np.random.seed(args.seed + rank)   # experts / start epochs differ per rank, synthetic set does not
+    # world > 1 without --distributed: mode A (every rank its own expert, gradients averaged);
+    # with --distributed: mode B = the reference flag's meaning (nn.DataParallel, distill.py:443-445):
+    # every rank a chunk of each minibatch, SAME expert / start epoch / permutations everywhere
+    mode_b = bool(args.distributed) and world > 1
+    np.random.seed(args.seed + (0 if mode_b else rank))
     if args.image_encoder not in VARIANTS:
         raise NotImplementedError("hot path encoders: %s" % sorted(VARIANTS))
     variant = VARIANTS[args.image_encoder]
     d_txt = 768 if args.text_encoder == "bert" else 512
     batch = min(args.mini_batch_size, args.num_queries)
+    if mode_b and batch % world:
+        raise ValueError("--distributed: mini_batch_size %d is not divisible by %d ranks" % (batch, world))
+    if mode_b and args.engine != "fused":
+        raise NotImplementedError("--distributed sample sharding runs on the fused engine passes")
 
-    eng = UnrollEngine(variant, batch=batch, num_queries=args.num_queries, image_size=args.image_size,
+    eng = UnrollEngine(variant, batch=batch // world if mode_b else batch, num_queries=args.num_queries,
+                       image_size=args.image_size,
                        d_txt=d_txt, syn_steps=args.syn_steps, dtype=args.compute_dtype, device=device)
     lib = _lib.load()
     image_syn, text_syn = init_synthetic_set(args, d_txt, device)
@@ -211,7 +220,7 @@ def main(args):
     # ---- expert buffers (distill.py:255-283)
     if args.synthetic_experts:
         E, T = args.synthetic_experts
-        buf = synthetic_buffer(eng, E, T, seed=args.seed + rank, device=device)
+        buf = synthetic_buffer(eng, E, T, seed=args.seed + (0 if mode_b else rank), device=device)
         files = None
     else:
         img_files, txt_files = list_expert_files(args.buffer_path)
@@ -255,7 +264,16 @@ def main(args):
         th0i, th0t, tgi, tgt = buf.pick(e_idx, start_epoch, args.expert_epochs)
         perms = torch.stack([torch.randperm(args.num_queries)[:batch] for _ in range(args.syn_steps)]).to(device)
 
-        if args.engine == "fused":
+        if mode_b:
+            from . import parallel as par
+            gm = torch.Generator(device=device).manual_seed(args.seed * 1_000_003 + it)   # same masks on every rank
+            masks = (torch.rand(args.syn_steps, batch, eng.feature_dim, device=device, generator=gm) >= 0.1).float() / 0.9
+            ob = par.run_collectives(par.sharded_unrolled_match(
+                eng, rank, world, image_syn, text_syn, lr, th0i, th0t, tgi, tgt, perms, drop_masks=masks,
+                logit_scale=args.logit_scale))
+            out["image_syn"].copy_(ob["image_syn"]), out["text_syn"].copy_(ob["text_syn"]), out["lr"].copy_(ob["lr"])
+            losses = torch.cat([torch.stack([ob["grand_loss"], ob["img_loss"], ob["txt_loss"]]), ob["contrastive"]])
+        elif args.engine == "fused":
             masks = None
             if True:  # the student text projection is in train mode (distill.py:446-447): Dropout(0.1)
                 masks = (torch.rand(args.syn_steps, batch, eng.feature_dim, device=device) >= 0.1).float() / 0.9
@@ -273,7 +291,7 @@ def main(args):
             out["image_syn"].copy_(gi), out["text_syn"].copy_(gt_)
             out["lr"].copy_(torch.stack([gli, glt]))
             losses = torch.stack([grand.detach(), il.detach(), tl.detach()] + ces)
-        if world > 1:
+        if world > 1 and not mode_b:
             dist.all_reduce(grads)
             grads.div_(world)
         # NaN -> leave the loop (distill.py:599-600); one host sync per iteration

@@ -35,3 +35,142 @@ def shared_permutations(num_queries, batch, syn_steps, iteration, seed=0):
     """Minibatch indices (distill.py:510-511) drawn identically on every rank."""
     g = torch.Generator().manual_seed(seed * 1_000_003 + iteration)
     return torch.stack([torch.randperm(num_queries, generator=g)[:batch] for _ in range(syn_steps)])
+
+
+# ----------------------------------------------------------------------------------------------
+# Mode B (SURVEY 8e): synthetic-sample sharding = what the reference's `--distributed` does with
+# nn.DataParallel (distill.py:443-445, 515-517): every rank runs the SAME unrolled loop on its chunk of
+# each step's minibatch with replicated theta, and the ranks exchange
+#   per step, forward sweep : all-gather of the two [n_loc, D] feature blocks (the N x N logits need every
+#                             row), all-reduce(sum) of the inner gradient (P_img + P_txt floats)
+#   per step, reverse sweep : the same two exchanges for the tangent features and the Hessian-vector rows
+#   per iteration           : all-reduce(sum) of d image_syn / d text_syn (each rank holds its rows' part)
+# Results equal the single-GPU iteration up to summation order.  Costlier than mode A (2*K all-reduces of
+# 159 MB per iteration at C2) -- it exists for parity with the reference's flag, not for speed.
+#
+# The iteration is a GENERATOR that yields ("all_gather" | "all_reduce", tensor) at every exchange and is
+# sent the result back, so the same code runs under torch.distributed (`run_collectives`) and, for tests on
+# one GPU, as several lock-stepped shards in one process (`run_lockstep`).
+def _op_contrastive(lib, x, y, scale, xd=None, yd=None):
+    import ctypes as C
+    from . import _lib
+    n, d = x.shape
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    work = torch.empty(lib.mdd_op_contrastive_workspace_floats(n, d), device=x.device)
+    loss = torch.zeros(1, device=x.device)
+    xb, yb, sb = torch.empty_like(x), torch.empty_like(y), torch.zeros(1, device=x.device)
+    sdev, sconst = (scale, 0.0) if torch.is_tensor(scale) else (None, float(scale))
+    _lib.check(lib.mdd_op_contrastive(n, d, P(x), P(y), P(xd), P(yd), P(sdev), sconst, P(work), P(loss),
+                                      P(xb), P(yb), P(sb), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return loss, xb, yb, sb
+
+
+def sharded_unrolled_match(eng, rank, world, image_syn, text_syn, lr, theta0_img, theta0_txt, target_img,
+                           target_txt, perms, drop_masks=None, logit_scale=None):
+    """One outer iteration (reference distill.py:509-606) on shard `rank` of `world`.
+    eng: UnrollEngine(batch = minibatch/world, num_queries = len(image_syn)); image_syn/text_syn/theta/lr
+    replicated; perms [K, minibatch] and drop_masks [K, minibatch, D] are the FULL minibatch's, identical
+    on every rank.  Returns dict(grand_loss, img_loss, txt_loss, contrastive [K], image_syn, text_syn, lr)
+    with the synthetic-set gradients already summed over ranks."""
+    from . import _lib
+    lib = _lib.load()
+    K, B = perms.shape
+    nl = eng.batch
+    assert B == nl * world and eng.syn_steps >= K
+    lo, hi = rank * nl, (rank + 1) * nl
+    lr_img, lr_txt = lr[0:1], lr[1:2]
+    scale = lr_img if logit_scale is None else float(logit_scale)
+    thI, thT, gI, gT, feats, ces = [theta0_img], [theta0_txt], [], [], [], []
+    # ---- unrolled student training
+    for k in range(K):
+        idx = perms[k, lo:hi].contiguous()
+        mask = None if drop_masks is None else drop_masks[k, lo:hi].contiguous()
+        x = eng.img_forward(k, thI[k], image_syn, idx=idx)
+        y = eng.txt_forward(k, thT[k], text_syn, idx=idx, drop_mask=mask)
+        X = yield ("all_gather", x)
+        Y = yield ("all_gather", y)
+        loss, xb, yb, _ = _op_contrastive(lib, X, Y, scale)
+        ces.append(loss)
+        feats.append((X, Y))
+        g_i = yield ("all_reduce", eng.img_backward(k, thI[k], xb[lo:hi].contiguous()))
+        g_t = yield ("all_reduce", eng.txt_backward(k, thT[k], yb[lo:hi].contiguous()))
+        gI.append(g_i), gT.append(g_t)
+        thI.append(thI[k] - lr_img * g_i)          # distill.py:582-583
+        thT.append(thT[k] - lr_txt * g_t)
+    # ---- trajectory-matching loss (distill.py:584-598), fp64 accumulation like the fused path
+    d0i = (theta0_img.double() - target_img.double()).pow(2).sum()
+    d0t = (theta0_txt.double() - target_txt.double()).pow(2).sum()
+    img_loss = (thI[K].double() - target_img.double()).pow(2).sum() / d0i
+    txt_loss = (thT[K].double() - target_txt.double()).pow(2).sum() / d0t
+    # ---- outer backward as an explicit reverse sweep (see DESIGN.md section 2)
+    lamI = (2.0 * (thI[K].double() - target_img.double()) / d0i).float()
+    lamT = (2.0 * (thT[K].double() - target_txt.double()) / d0t).float()
+    g_image, g_text = torch.zeros_like(image_syn), torch.zeros_like(text_syn)
+    dlr = torch.zeros(2, dtype=torch.float64, device=image_syn.device)
+    for k in range(K - 1, -1, -1):
+        idx = perms[k, lo:hi].contiguous()
+        dlr[0] -= torch.dot(gI[k].double(), lamI.double())
+        dlr[1] -= torch.dot(gT[k].double(), lamT.double())
+        nuI, nuT = (lr_img * lamI).contiguous(), (lr_txt * lamT).contiguous()
+        xd = eng.img_tangent_forward(k, thI[k], nuI)
+        yd = eng.txt_tangent_forward(k, thT[k], nuT)
+        Xd = yield ("all_gather", xd)
+        Yd = yield ("all_gather", yd)
+        X, Y = feats[k]
+        _, xbd, ybd, sbd = _op_contrastive(lib, X, Y, scale, Xd, Yd)
+        hI = yield ("all_reduce", eng.img_tangent_backward(k, thI[k], nuI, xbd[lo:hi].contiguous(),
+                                                           dimage=g_image, idx=idx, mul=-1.0))
+        hT = yield ("all_reduce", eng.txt_tangent_backward(k, thT[k], nuT, ybd[lo:hi].contiguous(),
+                                                           dtext=g_text, idx=idx, mul=-1.0))
+        if logit_scale is None:
+            dlr[0] -= sbd[0].double()              # the fork's logit scale IS syn_lr_img (distill.py:548)
+        lamI, lamT = lamI - hI, lamT - hT
+    g_image = yield ("all_reduce", g_image)
+    g_text = yield ("all_reduce", g_text)
+    return dict(grand_loss=(img_loss + txt_loss).float(), img_loss=img_loss.float(), txt_loss=txt_loss.float(),
+                contrastive=torch.cat(ces), image_syn=g_image, text_syn=g_text, lr=dlr.float())
+
+
+def run_collectives(gen, group=None):
+    """Drive one shard's generator with torch.distributed collectives (nccl = RCCL on the GPUs)."""
+    world = dist.get_world_size(group)
+    res = None
+    try:
+        while True:
+            op, t = gen.send(res)
+            if op == "all_gather":
+                parts = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(parts, t.contiguous(), group=group)
+                res = torch.cat(parts, 0)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                res = t
+    except StopIteration as e:
+        return e.value
+
+
+def run_lockstep(gens):
+    """Drive the generators of ALL shards in one process (tests): every shard reaches the same exchange,
+    the collective is evaluated on their tensors, each is sent the result."""
+    res = [None] * len(gens)
+    outs = [None] * len(gens)
+    live = True
+    while live:
+        reqs = []
+        for i, g in enumerate(gens):
+            try:
+                reqs.append(g.send(res[i]))
+            except StopIteration as e:
+                outs[i] = e.value
+                live = False
+        if not live:
+            assert all(o is not None for o in outs), "shards left the iteration at different exchanges"
+            return outs
+        ops = {r[0] for r in reqs}
+        assert len(ops) == 1, "shards disagree on the collective"
+        if ops.pop() == "all_gather":
+            full = torch.cat([r[1] for r in reqs], 0)
+            res = [full] * len(gens)
+        else:
+            tot = torch.stack([r[1] for r in reqs], 0).sum(0)
+            res = [tot.clone() for _ in gens]

@@ -178,3 +178,47 @@ def test_distill_cli_breaks_on_nan_like_the_reference(capsys, tmp_path, monkeypa
     assert "NaN" in out and "iteration 0" in out
     assert torch.isfinite(img).all() and torch.isfinite(txt).all() and torch.isfinite(lr).all()
     nw.release_engines()
+
+
+def test_mode_b_sample_sharding_matches_the_single_gpu_iteration(report):
+    """SURVEY 8e mode B (the reference's --distributed / DataParallel semantics, distill.py:443-445,
+    515-517): two shards of every minibatch with all-gathered features and all-reduced gradients must give
+    the oracle's full-batch iteration.  The shards run lock-stepped in one process on one GPU
+    (parallel.run_lockstep); under torch.distributed the same generator is driven by run_collectives."""
+    from multimodal_dataset_distillation_amd import parallel as par
+    from multimodal_dataset_distillation_amd.engine import UnrollEngine
+    from oracle import distill_ref as dr
+    from test_gpu_engine import make_oracle
+    nq, B, world, size, d_txt, K = 6, 4, 2, 64, 32, 2
+    fi, ft = make_oracle("nfnet_tiny", d_txt, 31)
+    feat = ft.module.fc.out_features
+    img, txt = dr.synthetic_inputs(nq, size, d_txt, seed=12)
+    g = torch.Generator().manual_seed(8)
+    perms = torch.stack([torch.randperm(nq, generator=g)[:B] for _ in range(K)])
+    masks = torch.stack([(torch.rand(B, feat, generator=g) >= 0.1).float() / 0.9 for _ in range(K)])
+    th0i, th0t = fi.flat_param(), ft.flat_param()
+    tgi = th0i + 2e-3 * torch.randn(th0i.shape, generator=g)
+    tgt = th0t + 2e-3 * torch.randn(th0t.shape, generator=g)
+    im, tx = img.clone().requires_grad_(True), txt.clone().requires_grad_(True)
+    lri = torch.tensor(0.1, requires_grad=True); lrt = torch.tensor(0.07, requires_grad=True)
+    grand, info = dr.unrolled_match(fi, ft, im, tx, lri, lrt, th0i, th0t, tgi, tgt, list(perms), drop_masks=list(masks))
+    gi, gt_, gli, glt = dr.outer_grads(grand, im, tx, lri, lrt)
+    dev = "cuda"
+    engs = [UnrollEngine("nfnet_tiny", batch=B // world, num_queries=nq, image_size=size, d_txt=d_txt,
+                         syn_steps=K, dtype="f32") for _ in range(world)]
+    lr = torch.tensor([0.1, 0.07], device=dev)
+    D = lambda t: t.to(dev)
+    gens = [par.sharded_unrolled_match(engs[r], r, world, D(img), D(txt), lr, D(th0i), D(th0t), D(tgi), D(tgt),
+                                       D(perms), drop_masks=D(masks)) for r in range(world)]
+    outs = par.run_lockstep(gens)
+    torch.cuda.synchronize()
+    for r, out in enumerate(outs):
+        e = dict(grand=abs(out["grand_loss"].item() - grand.item()) / abs(grand.item()),
+                 ces=rel_err(out["contrastive"], torch.stack(info["contrastive"])),
+                 g_img=rel_err(out["image_syn"], gi), g_txt=rel_err(out["text_syn"], gt_),
+                 g_lri=abs(out["lr"][0].item() - gli.item()) / abs(gli.item()),
+                 g_lrt=abs(out["lr"][1].item() - glt.item()) / abs(glt.item()))
+        report(f"mode B shard {r}/{world} vs oracle full batch: " + " ".join(f"{k} {float(v):.2e}" for k, v in e.items()))
+        assert all(float(v) < 1e-3 for v in e.values()), e
+    for e_ in engs:
+        e_.close()

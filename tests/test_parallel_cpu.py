@@ -60,3 +60,40 @@ def test_two_rank_gradient_averaging_and_identical_updates():
         return torch.cat([torch.randn(6, 3, 8, 8, generator=g).flatten(),
                           torch.randn(6, 5, generator=g).flatten(), torch.randn(2, generator=g)])
     assert torch.allclose(a["flat"], 0.5 * (grad(4) + grad(0)), atol=1e-6)
+
+
+def _toy_shard(rank, world, base):
+    """A stand-in for parallel.sharded_unrolled_match with the same exchange protocol: gather the ranks'
+    feature rows, reduce a rank-specific gradient, twice, and return what it was sent."""
+    x = base[rank * 2:(rank + 1) * 2] * (rank + 1)
+    X = yield ("all_gather", x)
+    g = yield ("all_reduce", X.sum(0) * (rank + 1))
+    X2 = yield ("all_gather", X[rank:rank + 1] + g[:1])
+    h = yield ("all_reduce", torch.full((3,), float(rank + 1)))
+    return dict(X=X, g=g, X2=X2, h=h)
+
+
+def _worker_b(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multimodal_dataset_distillation_amd import parallel as par
+    base = torch.arange(12, dtype=torch.float32).view(4, 3)
+    out[rank] = par.run_collectives(_toy_shard(rank, world, base))
+    dist.destroy_process_group()
+
+
+def test_mode_b_collective_driver_equals_the_lockstep_driver():
+    """parallel.run_collectives (torch.distributed, 2 gloo ranks) and parallel.run_lockstep (all shards in
+    one process; what the GPU parity test of mode B uses) must feed a shard generator the same tensors."""
+    from multimodal_dataset_distillation_amd import parallel as par
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_b, args=(world, _free_port(), out), nprocs=world, join=True)
+    base = torch.arange(12, dtype=torch.float32).view(4, 3)
+    want = par.run_lockstep([_toy_shard(r, world, base) for r in range(world)])
+    for r in range(world):
+        for k in ("X", "g", "X2", "h"):
+            assert torch.equal(out[r][k], want[r][k]), (r, k)
+    assert torch.equal(out[0]["X"], out[1]["X"]) and torch.equal(out[0]["h"], torch.full((3,), 3.0))
