@@ -17,12 +17,16 @@
 // caller).  An optional second pair (dy2, x2) is accumulated too (tangent pass), and the bias
 // gradient (column sums of dy1) is taken from the staging registers of the k'-tile-0 blocks.
 #include <cstdint>
+#include <type_traits>
 #include <cstdlib>
 
 #include "kernels.h"
 
 #ifndef MDD_WG_SINGLE_BUF
 #define MDD_WG_SINGLE_BUF 1
+#endif
+#ifndef MDD_WG_PF2
+#define MDD_WG_PF2 0
 #endif
 #ifndef MDD_WG_MIN_WAVES
 #define MDD_WG_MIN_WAVES 1
@@ -43,7 +47,8 @@ typedef unsigned __attribute__((ext_vector_type(4))) u32x4;   // first-class 16-
 template <int ROWB> DEVI int wswz(int row) { return ROWB == 128 ? ((row >> 1) & 3) : (row & 7); }
 
 // PW: pointwise (1x1, stride 1, no padding) instance -- no gather state, no per-step pixel decode
-template <class AT, int BCO, int BKP, int BKM, bool PW>
+// PF2: two tiles in flight in staging registers (loads issued two K-steps before their LDS store)
+template <class AT, int BCO, int BKP, int BKM, bool PW, bool PF2>
 __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArgs p) {
   constexpr int CE = 16 / (int)sizeof(AT);
   constexpr bool BF = sizeof(AT) == 2;
@@ -138,14 +143,17 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
   };
   if constexpr (!pointwise) init_rows();
 
-  u32x4 rd[DSL], rx[XSL];
-  bool bias_now = false;
+  constexpr int NST = PF2 ? 2 : 1;
+  u32x4 rdS[NST][DSL], rxS[NST][XSL];
+  bool biasS[NST] = {};
   float bsum[CE];
 #pragma unroll
   for (int e = 0; e < CE; ++e) bsum[e] = 0.f;
   const bool do_bias = p.dbias != nullptr && kpt == 0;
 
-  auto load_tile = [&](int it) {
+  auto load_tile = [&](auto SI, int it) {
+    constexpr int si = decltype(SI)::value;
+    u32x4* rd = rdS[si]; u32x4* rx = rxS[si];
     const bool second = it >= niter1;
     if constexpr (!pointwise) { if (it == niter1) init_rows(); }
     const int itl = second ? it - niter1 : it;
@@ -176,9 +184,12 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
       }
       rx[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx_, (int)(ok ? vo : OOB), so, 0));
     }
-    bias_now = do_bias && !second;
+    biasS[si] = do_bias && !second;
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](auto SI, int buf) {
+    constexpr int si = decltype(SI)::value;
+    const u32x4* rd = rdS[si]; const u32x4* rx = rxS[si];
+    const bool bias_now = biasS[si];
     char* d = Ds + buf * DTILE;
     char* x = Xs + buf * XTILE;
 #pragma unroll
@@ -217,15 +228,20 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
 #pragma unroll
       for (int r = 0; r < 4; ++r) accb[i][j][r] = 0.f;
 
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, PF2 ? 1 : 0>;
   if (niter > 0) {
-    load_tile(0);
-    store_tile(0);
+    load_tile(S0{}, 0);
+    if (PF2 && niter > 1) load_tile(S1{}, 1);
+    store_tile(S0{}, 0);
   }
   __syncthreads();
 
-  for (int it = 0; it < niter; ++it) {
+  // one K-step: tile `it` is in LDS; the staging set SN holds tile it+1; (PF2) the free set SF takes it+2
+  auto step = [&](auto SF, auto SN, int it) {
     const int buf = NBUF == 2 ? (it & 1) : 0;
-    if (it + 1 < niter) load_tile(it + 1);
+    if constexpr (PF2) { if (it + 2 < niter) load_tile(SF, it + 2); }
+    else { if (it + 1 < niter) load_tile(SN, it + 1); }
     const char* d = Ds + buf * DTILE;
     const char* x = Xs + buf * XTILE;
     if constexpr (!BF) {
@@ -276,8 +292,16 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
       }
     }
     if (NBUF == 1) __syncthreads();      // everyone is done reading the tile before it is replaced
-    if (it + 1 < niter) store_tile(NBUF == 2 ? (buf ^ 1) : 0);
+    if (it + 1 < niter) store_tile(SN, NBUF == 2 ? (buf ^ 1) : 0);
     __syncthreads();
+  };
+  if constexpr (PF2) {
+    for (int it = 0; it < niter; it += 2) {
+      step(S0{}, S1{}, it);
+      if (it + 1 < niter) step(S1{}, S0{}, it + 1);
+    }
+  } else {
+    for (int it = 0; it < niter; ++it) step(S0{}, S0{}, it);
   }
 
   if (p.dbg & 2) return;   // dbg bit1: no write-out (timing only)
@@ -362,8 +386,9 @@ void launch_cfg(WArgs a, hipStream_t st) {
   static const int dbg = [] { const char* e = getenv("MDD_DBG"); return e ? atoi(e) : 0; }();
   a.dbg = dbg;
   dim3 grid(tiles, splits);
-  if (pw) k_conv_wgrad<AT, BCO, BKP, BKM, true><<<grid, 256, 0, st>>>(a);
-  else k_conv_wgrad<AT, BCO, BKP, BKM, false><<<grid, 256, 0, st>>>(a);
+  constexpr bool PF2 = MDD_WG_PF2 && sizeof(AT) == 2 && BCO == 128;   // 2 waves/SIMD either way there
+  if (pw) k_conv_wgrad<AT, BCO, BKP, BKM, true, PF2><<<grid, 256, 0, st>>>(a);
+  else k_conv_wgrad<AT, BCO, BKP, BKM, false, false><<<grid, 256, 0, st>>>(a);
 }
 
 }  // namespace
