@@ -18,6 +18,7 @@
 // bf16: v_mfma_f32_32x32x16_bf16 ; f32 (parity mode): v_mfma_f32_32x32x2_f32 (exact fp32 FMA).
 // Fused epilogues (ConvEpi): bias, SiLU*beta, SiLU' / SiLU'' chain rule, residual adds.
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -344,92 +345,116 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
       bias[e] = b4.x; bias[e + 1] = b4.y; bias[e + 2] = b4.z; bias[e + 3] = b4.w;
     }
   }
-  // The output pointers may alias the stashed operands as far as the compiler can tell, so it
-  // will not hoist the loads of pass p+1 above the stores of pass p by itself: the loop is
-  // software-pipelined by hand -- all global loads of U passes are issued first (one 16-byte load
-  // per operand and pass in flight per lane), then the U passes are computed and stored.
+  // The epilogue body is instantiated once per ConvEpi mode and picked by ONE uniform switch, so each
+  // instance only contains the operand loads and the math of its mode (a generic body paid 16-byte
+  // selects for every absent operand, a mode switch per row pass and 64-bit row indices: +30..70 % on
+  // short-K launches against tools/micro/gemm_core.hip).  Within an instance the output pointers may
+  // alias the stashed operands as far as the compiler can tell, so it will not hoist the loads of pass
+  // p+1 above the stores of pass p by itself: the loop is software-pipelined by hand -- the global loads of
+  // U row passes are issued first, then the U passes are computed and stored.
   constexpr int NP = 32 / RPP;
   constexpr int U = NP < MDD_EPI_UNROLL ? NP : MDD_EPI_UNROLL;
-  const int mode = E.mode;
   const bool ldop = !(p.dbg & 8);                          // dbg bit3: no epilogue operand loads (timing only)
-  const bool need_c = ldop && out_act && mode != EPI_FWD;
-  const bool need_t = ldop && out_act && mode == EPI_BWD_T;
-  const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+  const bool nomath = (p.dbg & 16) != 0;                   // dbg bit4: no activation math (timing only)
+  const bool nostore = (p.dbg & 2) != 0;                   // dbg bit1: no stores (timing only)
+  const float beta = E.beta;
+  auto run = [&](auto EMc) __attribute__((always_inline)) {
+    constexpr int EM = decltype(EMc)::value;
+    constexpr bool HAS_C = EM == EPI_FWD_T || EM == EPI_BWD || EM == EPI_BWD_T;   // stashed pre-activation
+    constexpr bool HAS_T = EM == EPI_BWD_T;                                       // its tangent + a-bar
+    constexpr bool HAS_ACT = EM != EPI_BWD_LIN;
+    const bool use_a1 = add1 != nullptr && ldop && EM != EPI_FWD && EM != EPI_FWD_T;
+    const bool use_a2 = add2 != nullptr && ldop && HAS_ACT && out_act != nullptr;
+    const bool do_act = HAS_ACT && out_act != nullptr;
+    constexpr int UU = (EM == EPI_BWD_T && U > 2) ? U / 2 : U;   // four 16-byte operands per pass: fewer passes in flight
 #pragma unroll
-  for (int hi = 0; hi < TM; ++hi) {
-    // this wave's 32-row block hi of the accumulators -> its private LDS stage (aliases the K-loop
-    // buffers: the loop's final barrier has retired every read of them)
-    if (hi) __syncthreads();
+    for (int hi = 0; hi < TM; ++hi) {
+      // this wave's 32-row block hi of the accumulators -> its private LDS stage (aliases the K-loop
+      // buffers: the loop's final barrier has retired every read of them)
+      if (hi) __syncthreads();
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + j * 32 + l31] = acc[hi][j][r];
-    __syncthreads();
-    if (!ncol_ok) continue;
+        for (int r = 0; r < 16; ++r)
+          stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + j * 32 + l31] = acc[hi][j][r];
+      __syncthreads();
+      if (!ncol_ok) continue;
 #pragma unroll 1
-    for (int ps0 = 0; ps0 < NP; ps0 += U) {
-      size_t idx[U];
-      bool ok[U];
-      uint4 q_a1[U], q_c[U], q_ct[U], q_ab[U], q_a2[U];
+      for (int ps0 = 0; ps0 < NP; ps0 += UU) {
+        int idx[UU];
+        bool ok[UU];
+        uint4 q_a1[UU], q_c[UU], q_ct[UU], q_ab[UU], q_a2[UU];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int row = (ps0 + u) * RPP + lrow;
-        int m = m0 + wm * WROWS + hi * 32 + row;
-        ok[u] = m < e_M;
-        if constexpr (MODE == 2) {   // class-local pixel -> full-resolution output pixel
-          int oxc = m % e_wo, t = m / e_wo;
-          int oyc = t % e_ho, ni = t / e_ho;
-          m = (ni * G.ho + 2 * oyc + py) * G.wo + 2 * oxc + px;
+        for (int u = 0; u < UU; ++u) {
+          const int row = (ps0 + u) * RPP + lrow;
+          int m = m0 + wm * WROWS + hi * 32 + row;
+          ok[u] = m < e_M;
+          if constexpr (MODE == 2) {   // class-local pixel -> full-resolution output pixel
+            int oxc = m % e_wo, t = m / e_wo;
+            int oyc = t % e_ho, ni = t / e_ho;
+            m = (ni * G.ho + 2 * oyc + py) * G.wo + 2 * oxc + px;
+          }
+          idx[u] = m * G.co_tot + ch;          // < 2^31 elements for every tensor of the path
+          if (ok[u]) {
+            if (use_a1) q_a1[u] = *(const uint4*)(add1 + idx[u]);
+            if constexpr (HAS_C) { if (do_act && ldop) q_c[u] = *(const uint4*)(Cst + idx[u]); }
+            if constexpr (HAS_T) {
+              if (do_act && ldop) { q_ct[u] = *(const uint4*)(Ct + idx[u]); q_ab[u] = *(const uint4*)(Ab + idx[u]); }
+            }
+            if (use_a2) q_a2[u] = *(const uint4*)(add2 + idx[u]);
+          }
         }
-        idx[u] = (size_t)m * G.co_tot + ch;
-        q_a1[u] = (ok[u] && ldop && add1) ? *(const uint4*)(add1 + idx[u]) : z4;
-        q_c[u] = (ok[u] && need_c) ? *(const uint4*)(Cst + idx[u]) : z4;
-        q_ct[u] = (ok[u] && need_t) ? *(const uint4*)(Ct + idx[u]) : z4;
-        q_ab[u] = (ok[u] && need_t) ? *(const uint4*)(Ab + idx[u]) : z4;
-        q_a2[u] = (ok[u] && ldop && out_act && add2) ? *(const uint4*)(add2 + idx[u]) : z4;
-      }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (!ok[u]) continue;
-        const int row = (ps0 + u) * RPP + lrow;
-        float v[CE], t0[CE], t1[CE], t2[CE], o[CE];
+        for (int u = 0; u < UU; ++u) {
+          if (!ok[u]) continue;
+          const int row = (ps0 + u) * RPP + lrow;
+          float v[CE], t0[CE], t1[CE], t2[CE], o[CE];
 #pragma unroll
-        for (int e = 0; e < CE; e += 4) {
-          float4 s4 = *(const float4*)(stage + row * PITCH + lcol + e);
-          v[e] = s4.x + bias[e]; v[e + 1] = s4.y + bias[e + 1];
-          v[e + 2] = s4.z + bias[e + 2]; v[e + 3] = s4.w + bias[e + 3];
+          for (int e = 0; e < CE; e += 4) {
+            float4 s4 = *(const float4*)(stage + row * PITCH + lcol + e);
+            v[e] = s4.x + bias[e]; v[e + 1] = s4.y + bias[e + 1];
+            v[e + 2] = s4.z + bias[e + 2]; v[e + 3] = s4.w + bias[e + 3];
+          }
+          if (use_a1) {
+            Chunk<AT>::unpack(q_a1[u], t0);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) v[e] += t0[e];
+          }
+          if (out_raw && !nostore) *(uint4*)(out_raw + idx[u]) = Chunk<AT>::pack(v);
+          if constexpr (HAS_ACT) {
+            if (!do_act) continue;
+            if (nomath || (HAS_C && !ldop)) {
+#pragma unroll
+              for (int e = 0; e < CE; ++e) o[e] = v[e];
+            } else if constexpr (EM == EPI_FWD) {
+#pragma unroll
+              for (int e = 0; e < CE; ++e) o[e] = beta * silu_(v[e]);
+            } else if constexpr (EM == EPI_BWD_T) {
+              Chunk<AT>::unpack(q_c[u], t0); Chunk<AT>::unpack(q_ct[u], t1); Chunk<AT>::unpack(q_ab[u], t2);
+#pragma unroll
+              for (int e = 0; e < CE; ++e) o[e] = beta * (dsilu_(Dual(t0[e], t1[e])) * Dual(t2[e], v[e])).t;
+            } else {   // EPI_FWD_T, EPI_BWD
+              Chunk<AT>::unpack(q_c[u], t0);
+#pragma unroll
+              for (int e = 0; e < CE; ++e) o[e] = beta * dsilu_(t0[e]) * v[e];
+            }
+            if (use_a2) {
+              Chunk<AT>::unpack(q_a2[u], t0);
+#pragma unroll
+              for (int e = 0; e < CE; ++e) o[e] += t0[e];
+            }
+            if (!nostore) *(uint4*)(out_act + idx[u]) = Chunk<AT>::pack(o);
+          }
         }
-        if (add1) {
-          Chunk<AT>::unpack(q_a1[u], t0);
-#pragma unroll
-          for (int e = 0; e < CE; ++e) v[e] += t0[e];
-        }
-        if (out_raw && !(p.dbg & 2)) *(uint4*)(out_raw + idx[u]) = Chunk<AT>::pack(v);
-        if (!out_act) continue;
-        if (p.dbg & 16) {                                  // dbg bit4: no activation math (timing only)
-#pragma unroll
-          for (int e = 0; e < CE; ++e) o[e] = v[e];
-        } else if (mode == EPI_FWD) {
-#pragma unroll
-          for (int e = 0; e < CE; ++e) o[e] = E.beta * silu_(v[e]);
-        } else if (mode == EPI_BWD_T) {
-          Chunk<AT>::unpack(q_c[u], t0); Chunk<AT>::unpack(q_ct[u], t1); Chunk<AT>::unpack(q_ab[u], t2);
-#pragma unroll
-          for (int e = 0; e < CE; ++e) o[e] = E.beta * (dsilu_(Dual(t0[e], t1[e])) * Dual(t2[e], v[e])).t;
-        } else {   // EPI_FWD_T, EPI_BWD
-          Chunk<AT>::unpack(q_c[u], t0);
-#pragma unroll
-          for (int e = 0; e < CE; ++e) o[e] = E.beta * dsilu_(t0[e]) * v[e];
-        }
-        if (add2) {
-          Chunk<AT>::unpack(q_a2[u], t0);
-#pragma unroll
-          for (int e = 0; e < CE; ++e) o[e] += t0[e];
-        }
-        if (!(p.dbg & 2)) *(uint4*)(out_act + idx[u]) = Chunk<AT>::pack(o);
       }
     }
+  };
+  switch (E.mode) {
+    case EPI_FWD: run(std::integral_constant<int, EPI_FWD>{}); break;
+    case EPI_FWD_T: run(std::integral_constant<int, EPI_FWD_T>{}); break;
+    case EPI_BWD: run(std::integral_constant<int, EPI_BWD>{}); break;
+    case EPI_BWD_T: run(std::integral_constant<int, EPI_BWD_T>{}); break;
+    default: run(std::integral_constant<int, EPI_BWD_LIN>{}); break;
   }
 }
 
