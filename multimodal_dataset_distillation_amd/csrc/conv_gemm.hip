@@ -358,15 +358,17 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
   const bool nomath = (p.dbg & 16) != 0;                   // dbg bit4: no activation math (timing only)
   const bool nostore = (p.dbg & 2) != 0;                   // dbg bit1: no stores (timing only)
   const float beta = E.beta;
-  auto run = [&](auto EMc) __attribute__((always_inline)) {
+  auto run = [&](auto EMc, auto FTc) __attribute__((always_inline)) {
     constexpr int EM = decltype(EMc)::value;
+    constexpr bool FULLT = decltype(FTc)::value;   // every row of the block tile is a real output row
     constexpr bool HAS_C = EM == EPI_FWD_T || EM == EPI_BWD || EM == EPI_BWD_T;   // stashed pre-activation
     constexpr bool HAS_T = EM == EPI_BWD_T;                                       // its tangent + a-bar
     constexpr bool HAS_ACT = EM != EPI_BWD_LIN;
     const bool use_a1 = add1 != nullptr && ldop && EM != EPI_FWD && EM != EPI_FWD_T;
     const bool use_a2 = add2 != nullptr && ldop && HAS_ACT && out_act != nullptr;
     const bool do_act = HAS_ACT && out_act != nullptr;
-    constexpr int UU = (EM == EPI_BWD_T && U > 2) ? U / 2 : U;   // four 16-byte operands per pass: fewer passes in flight
+    // four 16-byte operands per pass (tangent backward) or the parity-class row remap (MODE 2): fewer passes in flight
+    constexpr int UU = ((EM == EPI_BWD_T || MODE == 2) && U > 2) ? U / 2 : U;
 #pragma unroll
     for (int hi = 0; hi < TM; ++hi) {
       // this wave's 32-row block hi of the accumulators -> its private LDS stage (aliases the K-loop
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
         for (int u = 0; u < UU; ++u) {
           const int row = (ps0 + u) * RPP + lrow;
           int m = m0 + wm * WROWS + hi * 32 + row;
-          ok[u] = m < e_M;
+          ok[u] = FULLT || m < e_M;
           if constexpr (MODE == 2) {   // class-local pixel -> full-resolution output pixel
             int oxc = m % e_wo, t = m / e_wo;
             int oyc = t % e_ho, ni = t / e_ho;
@@ -449,13 +451,20 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
       }
     }
   };
+  const bool full_tile = MODE != 2 && m0 + BM <= e_M;
+#define MDD_RUN(EMV)                                                                         \
+  do {                                                                                       \
+    if (MODE != 2 && full_tile) run(std::integral_constant<int, EMV>{}, std::true_type{});   \
+    else run(std::integral_constant<int, EMV>{}, std::false_type{});                         \
+  } while (0)
   switch (E.mode) {
-    case EPI_FWD: run(std::integral_constant<int, EPI_FWD>{}); break;
-    case EPI_FWD_T: run(std::integral_constant<int, EPI_FWD_T>{}); break;
-    case EPI_BWD: run(std::integral_constant<int, EPI_BWD>{}); break;
-    case EPI_BWD_T: run(std::integral_constant<int, EPI_BWD_T>{}); break;
-    default: run(std::integral_constant<int, EPI_BWD_LIN>{}); break;
+    case EPI_FWD: MDD_RUN(EPI_FWD); break;
+    case EPI_FWD_T: MDD_RUN(EPI_FWD_T); break;
+    case EPI_BWD: MDD_RUN(EPI_BWD); break;
+    case EPI_BWD_T: MDD_RUN(EPI_BWD_T); break;
+    default: MDD_RUN(EPI_BWD_LIN); break;
   }
+#undef MDD_RUN
 }
 
 
