@@ -614,13 +614,18 @@ struct Eng : mdd_engine {
       const Blk& B = blks[b]; BlockActs& pa = P.blk[b]; BlockActs& qa = Q.blk[b];
       const AT *x = P.X[b], *x_t = Q.X[b], *a = P.A[b], *a_t = Q.A[b];
       const AT *sc = x, *sc_t = x_t;
+      bool sc_forked = false;
       if (B.ds >= 0) {
+        // the shortcut (avg-pool + 1x1 conv) only meets the residual branch at the SE apply: it runs on
+        // the side stream, which is idle during forward passes
+        hipStream_t ss = st;
+        if (use_side) { fork(st); ss = side; sc_forked = true; }
         const AT *din = a, *din_t = a_t;
         if (B.stride == 2) {
-          launch_avgpool2<AT>(T ? qa.P : pa.P, T ? a_t : a, N, B.hin, B.hin, B.cin, 2, st);
+          launch_avgpool2<AT>(T ? qa.P : pa.P, T ? a_t : a, N, B.hin, B.hin, B.cin, 2, ss);
           din = pa.P; din_t = qa.P;
         }
-        conv_fwd(T, convs[B.ds], din, din_t, pa.SC, qa.SC, nullptr, nullptr, 1.f, th, th_t, st);
+        conv_fwd(T, convs[B.ds], din, din_t, pa.SC, qa.SC, nullptr, nullptr, 1.f, th, th_t, ss);
         sc = pa.SC; sc_t = qa.SC;
       }
       conv_fwd(T, convs[B.c1], a, a_t, pa.C1, qa.C1, pa.A1, qa.A1, 1.f, th, th_t, st);
@@ -636,6 +641,7 @@ struct Eng : mdd_engine {
                         T ? th_t + B.se.off_w2 : nullptr, th + B.se.off_b2,
                         T ? th_t + B.se.off_b2 : nullptr, N, rd, c, 2, lin_main, st);
       bool lastb = b == nb - 1;
+      if (sc_forked) join(st);
       launch_se_apply<AT>(pa.C3, T ? qa.C3 : nullptr, pa.gate, T ? qa.gate : nullptr, sc,
                           T ? sc_t : nullptr, P.X[b + 1], T ? Q.X[b + 1] : nullptr,
                           lastb ? nullptr : P.A[b + 1], (T && !lastb) ? Q.A[b + 1] : nullptr, ga,
