@@ -31,6 +31,9 @@
 #ifndef MDD_SINGLE_BUF
 #define MDD_SINGLE_BUF 1
 #endif
+#ifndef MDD_FRAG_PREFETCH
+#define MDD_FRAG_PREFETCH 1
+#endif
 #ifndef MDD_MIN_WAVES
 #define MDD_MIN_WAVES 3
 #endif
@@ -287,6 +290,31 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
     wrA ^= ABUF; wrB ^= BBUF;
   };
   auto compute = [&]() __attribute__((always_inline)) {
+    if constexpr (MDD_FRAG_PREFETCH && sizeof(AT) == 2 && MODE == 0) {
+    // the LDS fragments of K-slice q+1 are fetched before the MFMAs of slice q are issued (the scheduling
+    // barriers keep the compiler from sinking the fetch back next to its use): +11..14 % on the long-K,
+    // single-round shapes in tools/micro/gemm_core.hip, neutral elsewhere
+    u32x4 af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[0][i] = *(const u32x4*)(smem + rdA[0] + i * 4096);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[0][j] = *(const u32x4*)(smem + rdB[0] + j * 4096);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q < 3) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[(q + 1) & 1][i] = *(const u32x4*)(smem + rdA[q + 1] + i * 4096);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[(q + 1) & 1][j] = *(const u32x4*)(smem + rdB[q + 1] + j * 4096);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mma<AT>::step(af[q & 1][i], bf[q & 1][j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    } else {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       u32x4 af[TM], bf[TN];
@@ -298,6 +326,7 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) Mma<AT>::step(af[i], bf[j], acc[i][j]);
+    }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) { rdA[q] ^= ABUF; rdB[q] ^= BBUF; }

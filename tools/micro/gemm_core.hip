@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 3) void k_reg(const bf16* __restrict__ A, cons
 
 // =============================================================== REGT<WGM,WGN,NB>: register staging, WGM x WGN waves of
 // 64x64, NB LDS stages (1 = two barriers per step, 2 = one barrier per step)
-template <int WGM, int WGN, int NB, int LB>
+template <int WGM, int WGN, int NB, int LB, int PF = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, LB) void k_regt(const bf16* __restrict__ A, const bf16* __restrict__ B,
                                                              bf16* __restrict__ C, int M, int N, int K) {
   constexpr int NT = 64 * WGM * WGN, BM = 64 * WGM, BN = 64 * WGN;
@@ -175,17 +175,41 @@ __global__ __launch_bounds__(64 * WGM * WGN, LB) void k_regt(const bf16* __restr
     const int buf = NB == 2 ? (kt & 1) : 0;
     if (kt + 1 < nk) load(kt + 1);
     const char* base = smem + buf * STG;
+    if constexpr (PF == 0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      u32x4 af[2], bf[2];
+      for (int q = 0; q < 4; ++q) {
+        u32x4 af[2], bf[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *(const u32x4*)(base + rdA[q] + i * 4096);
+        for (int i = 0; i < 2; ++i) af[i] = *(const u32x4*)(base + rdA[q] + i * 4096);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bf[j] = *(const u32x4*)(base + rdB[q] + j * 4096);
+        for (int j = 0; j < 2; ++j) bf[j] = *(const u32x4*)(base + rdB[q] + j * 4096);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) mma(af[i], bf[j], acc[i][j]);
+          for (int j = 0; j < 2; ++j) mma(af[i], bf[j], acc[i][j]);
+      }
+    } else {
+      // fragments of slice q+1 are fetched from LDS before the MFMAs of slice q are issued
+      u32x4 af[2][2], bf[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[0][i] = *(const u32x4*)(base + rdA[0] + i * 4096);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[0][j] = *(const u32x4*)(base + rdB[0] + j * 4096);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q < 3) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) af[(q + 1) & 1][i] = *(const u32x4*)(base + rdA[q + 1] + i * 4096);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) bf[(q + 1) & 1][j] = *(const u32x4*)(base + rdB[q + 1] + j * 4096);
+        }
+        if (PF == 2) __builtin_amdgcn_sched_barrier(0);   // keep the fetch ahead of the MFMAs
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) mma(af[q & 1][i], bf[q & 1][j], acc[i][j]);
+        if (PF == 2) __builtin_amdgcn_sched_barrier(0);
+      }
     }
     if (NB == 1) __syncthreads();
     if (kt + 1 < nk) store(NB == 2 ? (buf ^ 1) : 0);
@@ -336,12 +360,13 @@ int main() {
     std::vector<Var> vars;
     hipFuncSetAttribute((const void*)k_reg, hipFuncAttributeMaxDynamicSharedMemorySize, 34816);
     vars.push_back({"REG(1 stage)", [&] { return timeit([&] { k_reg<<<grid, 256, 34816>>>(A, B, Cref, M, N, K); }); }, 1e30f, true});
-#define ADD_T(WGM, WGN, NB, LB, NAME)                                                                  \
+#define ADD_T(WGM, WGN, NB, LB, NAME) ADD_TP(WGM, WGN, NB, LB, 0, NAME)
+#define ADD_TP(WGM, WGN, NB, LB, PF, NAME)                                                                  \
     if (N % (64 * WGN) == 0) {                                                                         \
       int shm = NB * (64 * WGM + 64 * WGN) * 128; int epi = WGM * WGN * 32 * 68 * 4; if (shm < epi) shm = epi; \
-      hipFuncSetAttribute((const void*)k_regt<WGM, WGN, NB, LB>, hipFuncAttributeMaxDynamicSharedMemorySize, shm); \
+      hipFuncSetAttribute((const void*)k_regt<WGM, WGN, NB, LB, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, shm); \
       int g2 = ((M + 64 * WGM - 1) / (64 * WGM)) * (N / (64 * WGN));                                   \
-      vars.push_back({NAME, [=] { return timeit([=] { k_regt<WGM, WGN, NB, LB><<<g2, 64 * WGM * WGN, shm>>>(A, B, C, M, N, K); }); }, 1e30f, true}); \
+      vars.push_back({NAME, [=] { return timeit([=] { k_regt<WGM, WGN, NB, LB, PF><<<g2, 64 * WGM * WGN, shm>>>(A, B, C, M, N, K); }); }, 1e30f, true}); \
     }
 #define ADD_L(BK, NS, LB, NAME)                                                                        \
     if (K % BK == 0) {                                                                                 \
@@ -350,7 +375,7 @@ int main() {
       vars.push_back({NAME, [=] { return timeit([=] { k_lds<BK, NS, LB><<<grid, 256, shm>>>(A, B, C, M, N, K); }); }, 1e30f, true}); \
     }
     ADD_T(2, 2, 1, 3, "REGT 2x2 nb1") ADD_T(2, 2, 2, 2, "REGT 2x2 nb2") ADD_T(4, 2, 1, 2, "REGT 4x2 nb1")
-    ADD_T(4, 4, 1, 1, "REGT 4x4 nb1") ADD_L(64, 2, 2, "LDS bk64 x2") ADD_L(32, 3, 3, "LDS bk32 x3")
+    ADD_TP(2, 2, 1, 3, 1, "REGT 2x2 pf1") ADD_TP(2, 2, 1, 3, 2, "REGT 2x2 pf2") ADD_TP(4, 2, 1, 2, 1, "REGT 4x2 pf1") ADD_L(64, 2, 2, "LDS bk64 x2") ADD_L(32, 3, 3, "LDS bk32 x3")
     for (int round = 0; round < 3; ++round)
       for (auto& v : vars) { float t = v.run(); if (t < v.best) v.best = t; }
     for (size_t i = 0; i < vars.size(); ++i) {
