@@ -164,3 +164,27 @@ def test_nearest_neighbor_oracle_matches_reference_golden_and_sklearn():
     bank, query = rng.randn(300, 40), rng.randn(9, 40)
     want = [int(np.argmax(cosine_similarity(q.reshape(1, -1), bank))) for q in query]
     assert rr.nearest_neighbor(list(range(300)), query, bank) == want
+
+
+def test_bench_algorithmic_flops_match_the_network_spec():
+    """bench.py prices an iteration at syn_steps * 9 * 2 * MACs_fwd.  The per-image MAC count it
+    uses (4.2419 G for NFNet-l0 at 224x224) is re-derived here from the oracle's layers by running one image
+    through forward hooks; the text head's 7.08 M from its two linear layers."""
+    import bench
+    enc = nr.ImageEncoder("nfnet_l0")
+    macs = [0]
+
+    def hook(mod, inp, out):
+        w = mod.weight
+        macs[0] += out.shape[2] * out.shape[3] * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3]
+    hs = [m.register_forward_hook(hook) for m in enc.modules() if isinstance(m, nr.ScaledStdConv2d)]
+    with torch.no_grad():
+        enc(torch.zeros(1, 3, 224, 224))
+    for h in hs:
+        h.remove()
+    assert abs(macs[0] - 4.2419e9) / 4.2419e9 < 1e-4, macs[0]
+    head = 768 * 2304 + 2304 * 2304
+    assert abs(head - 7.08e6) / 7.08e6 < 2e-3
+    want = 8 * 9 * 2 * (100 * (macs[0] + head) + 100 * 100 * 2304)
+    assert abs(bench.algorithmic_flops_per_iter(100, 8) - want) / want < 1e-3
+    assert abs(bench.algorithmic_flops_per_iter(100, 8) - 61.2e12) / 61.2e12 < 2e-3
