@@ -223,7 +223,7 @@ template <int N_> struct WaitVm {
   static DEVI void go() { __builtin_amdgcn_s_waitcnt((N_ & 0xF) | ((N_ >> 4) << 14) | (0x7 << 4) | (0xF << 8)); }
 };
 
-template <int BK, int NS, int LB>
+template <int BK, int NS, int LB, int PF = 0>
 __global__ __launch_bounds__(256, LB) void k_lds(const bf16* __restrict__ A, const bf16* __restrict__ B,
                                                  bf16* __restrict__ C, int M, int N, int K) {
   constexpr int ROWB = BK * 2, CPR = ROWB / 16, RPI = 64 / CPR;   // row bytes, chunks/row, rows per wave-load
@@ -290,17 +290,40 @@ __global__ __launch_bounds__(256, LB) void k_lds(const bf16* __restrict__ A, con
     asm volatile("s_barrier" ::: "memory");     // NOT __syncthreads(): its fence would wait for the stages still in flight
     if (kt + NS - 1 < nk) issue(kt + NS - 1);     // overwrites the stage computed at step kt-1
     const char* base = smem + (kt % NS) * STAGE;
+    if constexpr (PF == 0) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      u32x4 af[2], bf[2];
+      for (int q = 0; q < NQ; ++q) {
+        u32x4 af[2], bf[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *(const u32x4*)(base + rdA[q] + i * 32 * ROWB);
+        for (int i = 0; i < 2; ++i) af[i] = *(const u32x4*)(base + rdA[q] + i * 32 * ROWB);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bf[j] = *(const u32x4*)(base + rdB[q] + j * 32 * ROWB);
+        for (int j = 0; j < 2; ++j) bf[j] = *(const u32x4*)(base + rdB[q] + j * 32 * ROWB);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) mma(af[i], bf[j], acc[i][j]);
+          for (int j = 0; j < 2; ++j) mma(af[i], bf[j], acc[i][j]);
+      }
+    } else {
+      u32x4 af[2][2], bf[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[0][i] = *(const u32x4*)(base + rdA[0] + i * 32 * ROWB);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[0][j] = *(const u32x4*)(base + rdB[0] + j * 32 * ROWB);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        if (q + 1 < NQ) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) af[(q + 1) & 1][i] = *(const u32x4*)(base + rdA[q + 1] + i * 32 * ROWB);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) bf[(q + 1) & 1][j] = *(const u32x4*)(base + rdB[q + 1] + j * 32 * ROWB);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) mma(af[q & 1][i], bf[q & 1][j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
   __syncthreads();
@@ -368,14 +391,15 @@ int main() {
       int g2 = ((M + 64 * WGM - 1) / (64 * WGM)) * (N / (64 * WGN));                                   \
       vars.push_back({NAME, [=] { return timeit([=] { k_regt<WGM, WGN, NB, LB, PF><<<g2, 64 * WGM * WGN, shm>>>(A, B, C, M, N, K); }); }, 1e30f, true}); \
     }
-#define ADD_L(BK, NS, LB, NAME)                                                                        \
+#define ADD_L(BK, NS, LB, NAME) ADD_LP(BK, NS, LB, 0, NAME)
+#define ADD_LP(BK, NS, LB, PF, NAME)                                                                        \
     if (K % BK == 0) {                                                                                 \
       int shm = NS * 2 * 128 * BK * 2; if (shm < 34816) shm = 34816;                                   \
-      hipFuncSetAttribute((const void*)k_lds<BK, NS, LB>, hipFuncAttributeMaxDynamicSharedMemorySize, shm); \
-      vars.push_back({NAME, [=] { return timeit([=] { k_lds<BK, NS, LB><<<grid, 256, shm>>>(A, B, C, M, N, K); }); }, 1e30f, true}); \
+      hipFuncSetAttribute((const void*)k_lds<BK, NS, LB, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, shm); \
+      vars.push_back({NAME, [=] { return timeit([=] { k_lds<BK, NS, LB, PF><<<grid, 256, shm>>>(A, B, C, M, N, K); }); }, 1e30f, true}); \
     }
     ADD_T(2, 2, 1, 3, "REGT 2x2 nb1") ADD_T(2, 2, 2, 2, "REGT 2x2 nb2") ADD_T(4, 2, 1, 2, "REGT 4x2 nb1")
-    ADD_TP(2, 2, 1, 3, 1, "REGT 2x2 pf1") ADD_TP(2, 2, 1, 3, 2, "REGT 2x2 pf2") ADD_TP(4, 2, 1, 2, 1, "REGT 4x2 pf1") ADD_L(64, 2, 2, "LDS bk64 x2") ADD_L(32, 3, 3, "LDS bk32 x3")
+    ADD_TP(2, 2, 1, 3, 2, "REGT 2x2 pf2")  ADD_L(64, 2, 2, "LDS bk64 x2") ADD_LP(64, 2, 2, 1, "LDS bk64 x2 pf") ADD_L(32, 3, 3, "LDS bk32 x3")
     for (int round = 0; round < 3; ++round)
       for (auto& v : vars) { float t = v.run(); if (t < v.best) v.best = t; }
     for (size_t i = 0; i < vars.size(); ++i) {
