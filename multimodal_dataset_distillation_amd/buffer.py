@@ -6,8 +6,12 @@ img_replay_buffer_{n}.pt` / `txt_replay_buffer_{n}.pt` = torch.save(list[expert]
 list[epoch] of list[Tensor]) (buffer.py:67-68, 94-95, 104-112).
 
 Expert training itself is first-order only and is NOT the hot path.  It reuses
-the hot path's kernels: one training step = engine forward (F) + inner gradient (B) + flat SGD axpy,
-with the reference's fixed logit scale 1/0.07 (networks.py:878).  Real Flickr30K/COCO batches need
+the hot path's kernels: one training step = engine forward (F) + inner gradient (B) + the flat SGD
+step with the reference's optimiser semantics -- torch.optim.SGD(lr, momentum=--mom,
+weight_decay=--l2) per network (buffer.py:59-60), rebuilt with lr*0.1 after epoch
+train_epochs//2+1 under --decay (buffer.py:97-101; the reference multiplies an undefined `lr`
+there -- the intent, both teacher learning rates x0.1 and fresh momentum buffers, is what runs
+here) -- and the reference's fixed logit scale 1/0.07 (networks.py:878).  Real Flickr30K/COCO batches need
 the dataset + frozen BERT embeddings, which do not exist offline, so the only data source wired up is
 `--synthetic_data` (random image / text-embedding pairs): good for exercising the pipeline and for
 producing buffers in the reference format on an MI355X, not for training useful experts.
@@ -86,15 +90,15 @@ def main(args):
     shapes_i = [s for _, s, _ in eng.param_table("img")]
     shapes_t = [s for _, s, _ in eng.param_table("txt")]
     g = torch.Generator(device=device).manual_seed(args.seed)
-    lr_i = torch.tensor([args.lr_teacher_img], device=device)
-    lr_t = torch.tensor([args.lr_teacher_txt], device=device)
-    from . import _lib
-    import ctypes as C
-    lib = _lib.load()
-    P = lambda t: C.c_void_p(t.data_ptr())
+    from .optim import sgd_step
     for it in range(args.num_experts):
         th_i, th_t = synthetic_expert_params(eng, args.seed * 100003 + it, device=device)
         snaps_i, snaps_t = [th_i.cpu()], [th_t.cpu()]          # buffer.py:67-68
+        # teacher_optim_img / teacher_optim_txt (buffer.py:59-60)
+        lr_i, lr_t = float(args.lr_teacher_img), float(args.lr_teacher_txt)
+        mom_i, mom_t = torch.zeros_like(th_i), torch.zeros_like(th_t)
+        first = True
+        lr_schedule = [args.train_epochs // 2 + 1]             # buffer.py:70
         for e in range(args.train_epochs):
             for _ in range(args.synthetic_data):
                 img = torch.randn(n, 3, args.image_size, args.image_size, device=device, generator=g)
@@ -106,10 +110,14 @@ def main(args):
                 _, xb, yb, _ = eng.contrastive(x, y, 1.0 / 0.07)   # networks.py:878
                 gi = eng.img_backward(0, th_i, xb)
                 gt = eng.txt_backward(0, th_t, yb)
-                st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-                _lib.check(lib.mdd_flat_axpy(P(th_i), P(th_i), P(gi), P(lr_i), -1.0, th_i.numel(), st))
-                _lib.check(lib.mdd_flat_axpy(P(th_t), P(th_t), P(gt), P(lr_t), -1.0, th_t.numel(), st))
+                sgd_step(th_i, gi, mom_i, lr_i, args.mom, args.l2, first)
+                sgd_step(th_t, gt, mom_t, lr_t, args.mom, args.l2, first)
+                first = False
             snaps_i.append(th_i.cpu()), snaps_t.append(th_t.cpu())   # buffer.py:94-95
+            if e in lr_schedule and args.decay:                      # buffer.py:97-101
+                lr_i *= 0.1
+                lr_t *= 0.1
+                first = True                                         # rebuilt optimisers: fresh momentum buffers
         k = 0
         while os.path.exists(os.path.join(save_dir, "img_replay_buffer_%d.pt" % k)):
             k += 1

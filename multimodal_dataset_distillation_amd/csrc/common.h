@@ -13,6 +13,15 @@
 #define DEVI __device__ __forceinline__
 #define WAVE 64
 
+// Work-skipping timing switches (drop K-steps / epilogue / loads / math / stores) exist ONLY in
+// experiment builds (build_ext.build_variant(..., ["MDD_DEBUG_SWITCHES"])): the product library
+// compiles them out, so no environment variable can turn a kernel into a partial no-op.
+#ifdef MDD_DEBUG_SWITCHES
+#define MDD_DBG_BITS(p) ((p).dbg)
+#else
+#define MDD_DBG_BITS(p) 0
+#endif
+
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;

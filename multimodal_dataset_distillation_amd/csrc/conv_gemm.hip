@@ -17,6 +17,7 @@
 // of a ds_read_b128 hits 16 distinct 16-byte slots of the 256-byte bank row (conflict-free).
 // bf16: v_mfma_f32_32x32x16_bf16 ; f32 (parity mode): v_mfma_f32_32x32x2_f32 (exact fp32 FMA).
 // Fused epilogues (ConvEpi): bias, SiLU*beta, SiLU' / SiLU'' chain rule, residual adds.
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
   const int ktot_w = G.k * G.k * G.kc;          // K length of one packed weight row
   const int ktot = e_kh * e_kw * G.kc;          // K extent this block reduces over
   const int nk1 = (ktot + KE - 1) / KE;
-  const int nk = (p.dbg & 1) ? 1 : (p.A2 ? 2 * nk1 : nk1);   // dbg bit0: single K-step (timing only)
+  const int nk = (MDD_DBG_BITS(p) & 1) ? 1 : (p.A2 ? 2 * nk1 : nk1);   // dbg bit0: single K-step (timing only)
 
   // ---- per-thread staging geometry, hoisted out of the K loop (the loop is instruction-issue
   // bound, not MFMA- or HBM-bound: every VALU op per load counts).
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
   constexpr int WROWS = TM * 32, WCOLS = TN * 32, PITCH = WCOLS + 4;
   constexpr int LPR = WCOLS / CE;      // lanes per output row
   constexpr int RPP = 64 / LPR;        // rows per pass
-  if (p.dbg & 4) return;   // dbg bit2: no epilogue at all (timing only)
+  if (MDD_DBG_BITS(p) & 4) return;   // dbg bit2: no epilogue at all (timing only)
   float* stage = (float*)smem + wave * (32 * PITCH);   // one 32-row MFMA block at a time
   const ConvEpi& E = p.ep;
   AT* out_raw = (AT*)E.out_raw;
@@ -383,9 +384,9 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
   // U row passes are issued first, then the U passes are computed and stored.
   constexpr int NP = 32 / RPP;
   constexpr int U = NP < MDD_EPI_UNROLL ? NP : MDD_EPI_UNROLL;
-  const bool ldop = !(p.dbg & 8);                          // dbg bit3: no epilogue operand loads (timing only)
-  const bool nomath = (p.dbg & 16) != 0;                   // dbg bit4: no activation math (timing only)
-  const bool nostore = (p.dbg & 2) != 0;                   // dbg bit1: no stores (timing only)
+  const bool ldop = !(MDD_DBG_BITS(p) & 8);                          // dbg bit3: no epilogue operand loads (timing only)
+  const bool nomath = (MDD_DBG_BITS(p) & 16) != 0;                   // dbg bit4: no activation math (timing only)
+  const bool nostore = (MDD_DBG_BITS(p) & 2) != 0;                   // dbg bit1: no stores (timing only)
   const float beta = E.beta;
   auto run = [&](auto EMc, auto FTc) __attribute__((always_inline)) {
     constexpr int EM = decltype(EMc)::value;
@@ -507,11 +508,15 @@ void launch_cfg(const KArgs& a, hipStream_t st) {
   size_t shm = (MDD_SINGLE_BUF ? 1 : 2) * (BM + BN) * 128;
   size_t shm_epi = 4 * (size_t)32 * (TN * 32 + 4) * sizeof(float);  // per-wave transpose, 32 rows at a time
   if (shm_epi > shm) shm = shm_epi;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_conv_gemm<AT, WGM, WGN, TM, TN, MODE, KFULL>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    attr_set = true;
+  // the dynamic-LDS limit is a per-device function attribute: set it once per (instance, device)
+  static std::atomic<uint64_t> attr_devs{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_conv_gemm<AT, WGM, WGN, TM, TN, MODE, KFULL>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e == hipSuccess) attr_devs.fetch_or(bit, std::memory_order_release);
   }
   int64_t blocks = (int64_t)k.mtiles * k.ntiles * a.g.groups;
   k_conv_gemm<AT, WGM, WGN, TM, TN, MODE, KFULL><<<(unsigned)blocks, 256, shm, st>>>(k);
@@ -527,8 +532,12 @@ void launch_conv_gemm(const ConvGeom& g, const AT* A1, const AT* B1, const AT* A
   a.g = g; a.ep = ep;
   a.M = g.nimg * g.ho * g.wo;
   a.mtiles = a.ntiles = 0;
+#ifdef MDD_DEBUG_SWITCHES
   static const int dbg = [] { const char* e = getenv("MDD_DBG"); return e ? atoi(e) : 0; }();
   a.dbg = dbg;
+#else
+  a.dbg = 0;
+#endif
   // tile selection by output-channel width per group
   // MODE 0: pointwise (pure GEMM) ; 1: taps at linear offsets (any forward conv, stride-1 dgrad) ;
   // 2: stride-2 data gradient.  KFULL: K is a whole number of 128-byte steps (no tail select).

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
   const int mbeg = bsplit * p.mchunk;
   const int mend = min(p.M, mbeg + p.mchunk);
   const int niter1 = mend > mbeg ? (mend - mbeg + BKM - 1) / BKM : 0;
-  const int niter = (p.dbg & 1) ? (niter1 > 0 ? 1 : 0) : (p.dy2 ? 2 * niter1 : niter1);   // dbg bit0: timing only
+  const int niter = (MDD_DBG_BITS(p) & 1) ? (niter1 > 0 ? 1 : 0) : (p.dy2 ? 2 * niter1 : niter1);   // dbg bit0: timing only
 
   // ---- staging geometry.  dy: chunk col dcol, rows drow + DSTEP*i ; x: xcol, rows xrow + XSTEP*i.
   // All global loads are BUFFER loads: a wave-uniform descriptor + a 32-bit per-lane byte offset that is
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
     for (int it = 0; it < niter; ++it) step(S0{}, S0{}, it);
   }
 
-  if (p.dbg & 2) return;   // dbg bit1: no write-out (timing only)
+  if (MDD_DBG_BITS(p) & 2) return;   // dbg bit1: no write-out (timing only)
   // ---- write-out: fp32 atomics into dW[g][co][k']
   float* dWg = p.dW + (size_t)grp * G.nc * ktot;
   if constexpr (!BF) {
@@ -383,8 +383,12 @@ void launch_cfg(WArgs a, hipStream_t st) {
   mchunk = ((mchunk + BKM - 1) / BKM) * BKM;
   splits = (a.M + mchunk - 1) / mchunk;
   a.mchunk = mchunk;
+#ifdef MDD_DEBUG_SWITCHES
   static const int dbg = [] { const char* e = getenv("MDD_DBG"); return e ? atoi(e) : 0; }();
   a.dbg = dbg;
+#else
+  a.dbg = 0;
+#endif
   dim3 grid(tiles, splits);
   constexpr bool PF2 = MDD_WG_PF2 && sizeof(AT) == 2 && BCO == 128;   // 2 waves/SIMD either way there
   if (pw) k_conv_wgrad<AT, BCO, BKP, BKM, true, PF2><<<grid, 256, 0, st>>>(a);

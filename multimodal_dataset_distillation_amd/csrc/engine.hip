@@ -40,6 +40,12 @@ int mdd_set_error_msg(int code, const char* msg) {
 #define CHECK_ARG(cond, msg) \
   do { if (!(cond)) return mdd_set_error_msg(2, "mdd: invalid argument: " msg); } while (0)
 #define POST_LAUNCH(what) HIP_CHECK_RET(hipGetLastError())
+// inside Eng<AT> walkers: launch errors + latched stream-ordering / event errors
+#define POST_WALK(what)                                  \
+  do {                                                   \
+    HIP_CHECK_RET(hipGetLastError());                    \
+    if (int rc_ = async_status()) return rc_;            \
+  } while (0)
 
 // ------------------------------------------------------------------------------------------ spec
 namespace {
@@ -409,8 +415,10 @@ struct Eng : mdd_engine {
     lin_txt = lin_scratch_carve(lin_mem[2]);
     HIP_CHECK_RET(hipStreamSynchronize(st));  // descs.data() is host memory
     if (!side) {
+#ifdef MDD_DEBUG_SWITCHES
       const char* env = getenv("MDD_SIDE_STREAM");
       use_side = !(env && env[0] == '0');
+#endif
       if (use_side) HIP_CHECK_RET(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
       if (use_side) HIP_CHECK_RET(hipStreamCreateWithFlags(&tside, hipStreamNonBlocking));
     }
@@ -443,26 +451,48 @@ struct Eng : mdd_engine {
   }
   std::vector<hipEvent_t> evs;
   size_t evi = 0;
+  // The stream-ordering helpers below are called from inside the walkers (void lambdas, queued
+  // closures); the first failing HIP call is latched here and turned into the pass's return code by
+  // ASYNC_CHECK at the end of every walker -- a failed event record / stream wait would otherwise
+  // silently drop a dependency between the main and the side stream.
+  hipError_t aerr = hipSuccess;
+  const char* aerr_what = "";
+  void ck(hipError_t e, const char* what) {
+    if (e != hipSuccess && aerr == hipSuccess) { aerr = e; aerr_what = what; }
+  }
+  int async_status() {
+    if (aerr == hipSuccess) return 0;
+    hipError_t e = aerr; aerr = hipSuccess;
+    return mdd_set_error(e, aerr_what);
+  }
   hipEvent_t next_event() {
     if (evs.size() < 512) {
-      hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableTiming); evs.push_back(e); return e;
+      hipEvent_t e = nullptr;
+      ck(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreateWithFlags");
+      if (e) { evs.push_back(e); return e; }
     }
-    return evs[evi++ % evs.size()];
+    return evs.empty() ? nullptr : evs[evi++ % evs.size()];
+  }
+  void order(hipStream_t waiter, hipStream_t signaller) {   // waiter waits for everything enqueued on signaller
+    hipEvent_t e = next_event();
+    if (!e) { ck(hipErrorOutOfMemory, "no event for stream ordering"); return; }
+    ck(hipEventRecord(e, signaller), "hipEventRecord");
+    ck(hipStreamWaitEvent(waiter, e, 0), "hipStreamWaitEvent");
   }
   void fork(hipStream_t st) {  // side waits for everything enqueued on st so far
     if (!use_side) return;
-    hipEvent_t e = next_event(); hipEventRecord(e, st); hipStreamWaitEvent(side, e, 0);
+    order(side, st);
   }
   void join(hipStream_t st) {  // st waits for everything enqueued on side so far
     if (!use_side) return;
-    hipEvent_t e = next_event(); hipEventRecord(e, side); hipStreamWaitEvent(st, e, 0);
+    order(st, side);
   }
   hipStream_t wstream(hipStream_t st) const { return use_side ? side : st; }
   const LinScratch& wlin() const { return use_side ? lin_side : lin_main; }
   hipStream_t tside = nullptr;   // text-projection stream
   void fork_to(hipStream_t to, hipStream_t from) {
     if (to == from) return;
-    hipEvent_t e = next_event(); hipEventRecord(e, from); hipStreamWaitEvent(to, e, 0);
+    order(to, from);
   }
   void join_from(hipStream_t from, hipStream_t to) { fork_to(to, from); }
 
@@ -471,7 +501,7 @@ struct Eng : mdd_engine {
   bool prof_on = false;
   std::vector<Prof> prof;
   void profile_enable(bool on) override {
-    for (auto& p : prof) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (auto& p : prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     prof.clear(); prof_on = on;
   }
   int profile_read(int kind, double* out) override {  // {launches, total ms, flops, bytes}
@@ -487,7 +517,11 @@ struct Eng : mdd_engine {
     if (!f) return mdd_set_error_msg(4, "mdd: cannot open profile dump file");
     fprintf(f, "kind,transposed,nsrc,M,nc,groups,kc,k,stride,ha,ho,ms,gflops,gbytes,tflops_s,gb_s\n");
     for (auto& p : prof) {
-      float ms = 0; hipEventSynchronize(p.b); hipEventElapsedTime(&ms, p.a, p.b);
+      float ms = 0;
+      if (hipEventSynchronize(p.b) != hipSuccess || hipEventElapsedTime(&ms, p.a, p.b) != hipSuccess) {
+        fclose(f);
+        return mdd_set_error_msg(4, "mdd: profile events could not be read");
+      }
       fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.3f,%.4f,%.1f,%.1f\n", p.kind, p.g.transposed,
               p.ns, p.g.nimg * p.g.ho * p.g.wo, p.g.nc, p.g.groups, p.g.kc, p.g.k, p.g.stride, p.g.ha,
               p.g.ho, ms, p.flops / 1e9, p.bytes / 1e9, p.flops / ms / 1e9, p.bytes / ms / 1e6);
@@ -508,10 +542,10 @@ struct Eng : mdd_engine {
     int nio = (e.out_raw ? 1 : 0) + (e.out_act ? 1 : 0) + (e.c ? 1 : 0) + (e.c_t ? 1 : 0) +
               (e.abar ? 1 : 0) + (e.add1 ? 1 : 0) + (e.add2 ? 1 : 0);
     p.bytes = (ain * ns + (double)L.packed() * ns + aout * nio) * sizeof(AT);
-    hipEventCreate(&p.a); hipEventCreate(&p.b);
-    hipEventRecord(p.a, st);
+    ck(hipEventCreate(&p.a), "hipEventCreate"); ck(hipEventCreate(&p.b), "hipEventCreate");
+    ck(hipEventRecord(p.a, st), "hipEventRecord");
     launch_conv_gemm<AT>(g, A1, B1, A2, B2, e, st);
-    hipEventRecord(p.b, st);
+    ck(hipEventRecord(p.b, st), "hipEventRecord");
     p.g = g; p.ns = ns; prof.push_back(p);
   }
   void wgrad(const ConvL& L, const ConvGeom& g, const AT* dy1, const AT* x1, const AT* dy2, const AT* x2,
@@ -522,10 +556,10 @@ struct Eng : mdd_engine {
     p.flops = 2.0 * conv_macs(L) * ns;
     double ain = (double)g.nimg * g.ha * g.wa * g.ca_tot, aout = (double)g.nimg * g.ho * g.wo * g.co_tot;
     p.bytes = (ain + aout) * ns * sizeof(AT) + (double)L.packed() * 4;
-    hipEventCreate(&p.a); hipEventCreate(&p.b);
-    hipEventRecord(p.a, st);
+    ck(hipEventCreate(&p.a), "hipEventCreate"); ck(hipEventCreate(&p.b), "hipEventCreate");
+    ck(hipEventRecord(p.a, st), "hipEventRecord");
     launch_conv_wgrad<AT>(g, dy1, x1, dy2, x2, dW, db, st);
-    hipEventRecord(p.b, st);
+    ck(hipEventRecord(p.b, st), "hipEventRecord");
     p.g = g; p.ns = ns; prof.push_back(p);
   }
 
@@ -652,7 +686,7 @@ struct Eng : mdd_engine {
     launch_final_pool<AT>(P.y, T ? feat_out : nullptr, P.CF, T ? Q.CF : nullptr, N, hwf, feat, st);
     if (!T && feat_out && feat_out != P.y)
       HIP_CHECK_RET(hipMemcpyAsync(feat_out, P.y, (size_t)N * feat * 4, hipMemcpyDeviceToDevice, st));
-    POST_LAUNCH("img_forward");
+    POST_WALK("img_forward");
     return 0;
   }
 
@@ -760,7 +794,7 @@ struct Eng : mdd_engine {
     join(st);
     launch_ws_backward(d_descs, (int)descs.size(), total_rows, th, T ? th_t : nullptr, dw,
                        T ? dw_t : nullptr, gout, st);
-    POST_LAUNCH("img_backward");
+    POST_WALK("img_backward");
     return 0;
   }
 
@@ -784,7 +818,7 @@ struct Eng : mdd_engine {
                   tt(t_lb), N, feat, 1e-5f, st);
     if (!T && feat_out && feat_out != P.ty)
       HIP_CHECK_RET(hipMemcpyAsync(feat_out, P.ty, (size_t)N * feat * 4, hipMemcpyDeviceToDevice, st));
-    POST_LAUNCH("txt_forward");
+    POST_WALK("txt_forward");
     return 0;
   }
   std::vector<const float*> slot_mask_ = std::vector<const float*>(64, nullptr);
@@ -816,7 +850,7 @@ struct Eng : mdd_engine {
                           tt(t_pw), nullptr, N, Dt, feat, lin_txt, st);
       launch_scatter_rows_axpy(dtext, xb, idx, coef, mul, N, Dt, st);
     }
-    POST_LAUNCH("txt_backward");
+    POST_WALK("txt_backward");
     return 0;
   }
 
@@ -829,7 +863,7 @@ struct Eng : mdd_engine {
                                nullptr, scale_dev, scale_const, N, feat, st);
     else launch_contrastive(w, nullptr, nullptr, nullptr, nullptr, xb, yb, sb, x, y, x_t, y_t,
                             scale_dev, scale_const, N, feat, st);
-    POST_LAUNCH("contrastive");
+    POST_WALK("contrastive");
     return 0;
   }
 
@@ -902,7 +936,7 @@ struct Eng : mdd_engine {
     }
     join_from(ts, st);
     launch_d2f(a->grad_lr, dsc + 4, 1.f, 0, 2, st);
-    POST_LAUNCH("unrolled_match");
+    POST_WALK("unrolled_match");
     return 0;
   }
 };

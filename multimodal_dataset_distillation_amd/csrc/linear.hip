@@ -172,8 +172,11 @@ __global__ __launch_bounds__(256, 4) void k_sgemm_small(const GArgs p) {
   // ---- split-K: fp32 atomics into this tile's (always-zero-between-launches) scratch accumulator;
   // the last block to arrive swaps the sums out (re-zeroing the scratch) and runs the epilogue.
   // No device-scope fence: on gfx950 that is a whole-L2 write-back + invalidate per block.  The
-  // accumulators are only ever touched by device-scope atomics, and a wave's atomics are acknowledged
-  // (s_waitcnt vmcnt(0), part of the barrier) before thread 0 bumps the arrival counter.
+  // accumulators are only ever touched by device-scope atomics (executed at the memory side), and EVERY
+  // wave drains its own atomics with an explicit s_waitcnt vmcnt(0) BEFORE the workgroup barrier that
+  // precedes thread 0's arrival-counter bump: s_barrier itself does not wait for outstanding VMEM, and a
+  // workgroup-scope fence lowers to nothing for global memory, so without the wait another block could
+  // see splits-1 arrivals and swap the sums out while these adds are still in flight.
   if (p.splits > 1) {
     const int tile = blockIdx.y * gridDim.x + blockIdx.x;
     float* mine = p.part + (size_t)tile * (BM * BN) + tid;
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(256, 4) void k_sgemm_small(const GArgs p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) atomicAdd(rsp + i, rs[i]);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's atomic adds have been performed
     __syncthreads();
     if (tid == 0) {
       unsigned prev = atomicAdd(&p.ctr[tile], 1u);

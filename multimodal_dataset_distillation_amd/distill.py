@@ -12,9 +12,16 @@ reference distill.py:288-620 for the HOT PATH rows of SURVEY 8a:
   trajectory-matching loss, NaN break      distill.py:584-600
   outer backward + 3x SGD(momentum=0.5)    distill.py:603-613
 
-Out of scope here (SURVEY 8f "next"): evaluation of the synthetic set, wandb logging, image grids,
-real-data initialisation (needs the dataset + a frozen BERT; offline neither exists) -- the
-synthetic set is initialised with upstream's noise init (distill_original.py:138-148).
+Either side of the hot path, wired to the on-disk inputs the reference uses:
+  real-pair initialisation   distill.py:97-105, 228   --txt_init real reads the train-caption cache
+                             {dataset}_{text_encoder}_train_text_embed.npz (key bert_test_embed,
+                             utils.py:885); --pix_init real additionally needs --train_images (a tensor
+                             file of the training images in annotation order: the dataset itself is
+                             not available offline).  Default: upstream's noise init
+                             (distill_original.py:138-148).
+  caption decode             distill.py:89-95, 244    nearest_neighbor() on the same cache
+  evaluation every eval_it   distill.py:293-357       epoch.evaluate_synset when --eval_data is given
+Not reproduced: wandb logging, image grids.
 The student is built ONCE (the reference rebuilds timm+BERT every iteration, distill.py:440).
 Multi-GPU: launch with torch.distributed.run; each rank matches its own expert trajectory and the
 synthetic-set gradient is averaged with one RCCL all-reduce per iteration (SURVEY 8e mode A).
@@ -104,6 +111,20 @@ def build_parser():
                         "--buffer_path (no dataset/pretrained weights exist offline)")
     p.add_argument("--save_dir", type=str, default=None)
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--dist_backend", default="nccl", choices=["nccl", "gloo"],
+                   help="torch.distributed backend under a launcher (nccl = RCCL; gloo lets several "
+                        "ranks share one GPU in tests)")
+    p.add_argument("--embed_dir", type=str, default=".",
+                   help="directory of the {dataset}_{text_encoder}_{text,train_text}_embed.npz caches "
+                        "(reference utils.py:885 reads them from the working directory)")
+    p.add_argument("--train_images", type=str, default=None,
+                   help="tensor file (.pt/.npy/.npz key 'images') [M,3,S,S] of the training images in "
+                        "annotation order, for --pix_init real")
+    p.add_argument("--train_sentences", type=str, default=None,
+                   help="text file, one training caption per line (annotation order), for the caption decode")
+    p.add_argument("--eval_data", type=str, default=None,
+                   help=".npz with the held-out retrieval set (images, txt2img[, bert_test_embed]); "
+                        "enables evaluate_synset every --eval_it iterations")
     return p
 
 
@@ -132,17 +153,73 @@ def nearest_neighbor(sentences, query_embeddings, database_embeddings, device="c
     return [sentences[i] for i in ids]
 
 
-def init_synthetic_set(args, d_txt, device):
-    """upstream noise init (distill_original.py:138-148)."""
-    if args.pix_init != "noise" or args.txt_init != "noise":
-        raise NotImplementedError(
-            "real-pair initialisation needs the dataset and a frozen BERT text encoder "
-            "(reference distill.py:97-105); neither is part of the MI355X hot path -- use noise init")
-    mean = torch.tensor([-0.0626, -0.0221, 0.0680]).view(1, 3, 1, 1)
-    std = torch.tensor([1.0451, 1.0752, 1.0539]).view(1, 3, 1, 1)
-    image_syn = torch.randn([args.num_queries, 3, args.image_size, args.image_size]) * std + mean
-    text_syn = torch.normal(mean=-0.0094, std=0.5253, size=(args.num_queries, d_txt))
-    return image_syn.to(device).contiguous(), text_syn.float().to(device).contiguous()
+def init_synthetic_set(args, d_txt, device, train_caption_embed=None):
+    """Synthetic-set initialisation.
+    'real' (the fork, distill.py:97-105 + :228): n random training pairs -- images from --train_images,
+    text = the frozen encoder's embedding of the pair's caption = row i of the train-caption cache.
+    'noise' (upstream, distill_original.py:138-148): per-channel Gaussian pixels, N(-0.0094, 0.5253) text.
+    The two sides can be mixed (upstream has separate --pix_init / --txt_init flags)."""
+    from .embed_cache import get_images_texts, load_tensor_file
+    image_syn = text_syn = None
+    if args.pix_init == "real" or args.txt_init == "real":
+        if train_caption_embed is None:
+            raise FileNotFoundError("real initialisation needs the train-caption embedding cache")
+        train_images = None
+        if args.pix_init == "real":
+            if not args.train_images:
+                raise FileNotFoundError(
+                    "--pix_init real needs --train_images (tensor file of the training images in annotation "
+                    "order); the dataset loader itself is outside the MI355X path")
+            train_images = load_tensor_file(args.train_images, key="images")
+            if tuple(train_images.shape[1:]) != (3, args.image_size, args.image_size):
+                raise ValueError("--train_images: expected [M,3,%d,%d], got %s"
+                                 % (args.image_size, args.image_size, tuple(train_images.shape)))
+        if train_caption_embed.shape[1] != d_txt:
+            raise ValueError("train caption embeddings are %d-d, the text encoder %r gives %d"
+                             % (train_caption_embed.shape[1], args.text_encoder, d_txt))
+        img_r, txt_r, _ = get_images_texts(args.num_queries, train_images, train_caption_embed)
+        if args.pix_init == "real":
+            image_syn = img_r
+        if args.txt_init == "real":
+            text_syn = txt_r
+    if image_syn is None:
+        mean = torch.tensor([-0.0626, -0.0221, 0.0680]).view(1, 3, 1, 1)
+        std = torch.tensor([1.0451, 1.0752, 1.0539]).view(1, 3, 1, 1)
+        image_syn = torch.randn([args.num_queries, 3, args.image_size, args.image_size]) * std + mean
+    if text_syn is None:
+        text_syn = torch.normal(mean=-0.0094, std=0.5253, size=(args.num_queries, d_txt))
+    return image_syn.float().to(device).contiguous(), text_syn.float().to(device).contiguous()
+
+
+def run_evaluation(args, it, image_syn, text_syn, syn_lr_img, eval_set, eval_eng_box, variant, d_txt, device):
+    """The evaluation block of reference distill.py:293-357: num_eval fresh students trained on the
+    current synthetic set (evaluate_synset), retrieval recalls printed per run and, with --std, as
+    mean/std.  eval_set = (test_images, bert_test_embed, img2txt, txt2img) on `device`."""
+    from .engine import UnrollEngine
+    from .epoch import evaluate_synset
+    print("-------------------------\nEvaluation")
+    print("image_model_train = %s, text_model_train = %s, iteration = %d" % (args.image_encoder, args.text_encoder, it))
+    if eval_eng_box[0] is None:
+        nb = min(args.batch_train, args.num_queries)
+        eval_eng_box[0] = UnrollEngine(variant, batch=nb, num_queries=args.num_queries, image_size=args.image_size,
+                                       d_txt=d_txt, syn_steps=1, dtype=args.compute_dtype, device=device)
+    eng_e = eval_eng_box[0]
+    test_images, test_embed, img2txt, txt2img = eval_set
+    keys = ("img_r1", "img_r5", "img_r10", "img_r_mean", "txt_r1", "txt_r5", "txt_r10", "txt_r_mean", "r_mean")
+    runs = []
+    for it_eval in range(args.num_eval):
+        lr_net = float(syn_lr_img)                      # args.lr_net = syn_lr_img.item()  (distill.py:312)
+        _, _, res = evaluate_synset(eng_e, image_syn.detach().clone(), text_syn.detach().clone(), test_images,
+                                    test_embed, img2txt, txt2img, lr_net=lr_net,
+                                    epoch_eval_train=args.epoch_eval_train, seed=args.seed * 1009 + it * 31 + it_eval)
+        print("Evaluate_%02d: Img R@1 = %.4f, Img R@5 = %.4f, Img R@10 = %.4f, Img R@Mean = %.4f, "
+              "Txt R@1 = %.4f, Txt R@5 = %.4f, Txt R@10 = %.4f, Txt R@Mean = %.4f, R@Mean = %.4f"
+              % ((it_eval,) + tuple(res[k] for k in keys)))
+        runs.append(res)
+    summary = {k: (float(np.mean([r[k] for r in runs])), float(np.std([r[k] for r in runs]))) for k in keys}
+    if args.std:
+        print("  ".join("Mean/%s = %.4f Std/%s = %.4f" % (k, summary[k][0], k, summary[k][1]) for k in keys))
+    return summary
 
 
 def reference_loop_iteration(img_net, txt_net, image_syn, text_syn, syn_lr_img, syn_lr_txt, th0_img,
@@ -180,12 +257,15 @@ def main(args):
     if not torch.cuda.is_available():
         raise RuntimeError("distill.py needs an MI355X; the engine has no CPU path")
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0)) % max(1, torch.cuda.device_count())
     dist = None
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # RCCL over xGMI
+        else:
+            dist.init_process_group(args.dist_backend)   # gloo: several ranks sharing one GPU (tests)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     args.device = str(device)
@@ -209,13 +289,36 @@ def main(args):
                        image_size=args.image_size,
                        d_txt=d_txt, syn_steps=args.syn_steps, dtype=args.compute_dtype, device=device)
     lib = _lib.load()
-    image_syn, text_syn = init_synthetic_set(args, d_txt, device)
+    from .embed_cache import load_embed_cache, load_eval_data
+    # ---- on-disk inputs around the loop (distill.py:221-229): caption-embedding caches
+    train_caption_embed = train_sentences = None
+    need_train_cache = args.pix_init == "real" or args.txt_init == "real" or args.train_sentences
+    if need_train_cache:
+        train_caption_embed = load_embed_cache(args, "train_text")
+    if args.train_sentences:
+        with open(args.train_sentences, "r", encoding="utf-8") as f:
+            train_sentences = [ln.rstrip("\n") for ln in f]
+        if len(train_sentences) != train_caption_embed.shape[0]:
+            raise ValueError("--train_sentences has %d lines, the train-caption cache %d rows"
+                             % (len(train_sentences), train_caption_embed.shape[0]))
+    eval_set, eval_eng_box = None, [None]
+    if args.eval_data:
+        ti, te, i2t, t2i = load_eval_data(args.eval_data, args)
+        eval_set = (ti.to(device).contiguous(), te.to(device).contiguous(), i2t, t2i)
+    eval_it_pool = set(np.arange(0, args.Iteration + 1, max(1, args.eval_it)).tolist())
+    image_syn, text_syn = init_synthetic_set(args, d_txt, device, train_caption_embed)
+    if train_sentences is not None and rank == 0:      # distill.py:244: decode of the initial text_syn
+        sl = nearest_neighbor(train_sentences, text_syn, train_caption_embed, device=device)
+        print("original_sentence_list:", " | ".join(sl[:5]), "..." if len(sl) > 5 else "")
     lr = torch.tensor([args.lr_teacher_img, args.lr_teacher_txt], device=device)  # syn_lr_img/txt
     n_img, n_txt = image_syn.numel(), text_syn.numel()
-    grads = torch.zeros(n_img + n_txt + 2, device=device)
+    from . import parallel as par
+    # [d image_syn | d text_syn | d lr (2) | NaN flag]: ONE buffer = one all-reduce per iteration in mode A
+    flat, views = par.fused_grad_buffer(image_syn, text_syn)
+    grads = views["grads"]
     mom = torch.zeros_like(grads)
-    out = dict(image_syn=grads[:n_img].view_as(image_syn), text_syn=grads[n_img:n_img + n_txt].view_as(text_syn),
-               lr=grads[n_img + n_txt:], losses=torch.zeros(3 + args.syn_steps, device=device))
+    out = dict(image_syn=views["image_syn"], text_syn=views["text_syn"], lr=views["lr"],
+               losses=torch.zeros(3 + args.syn_steps, device=device))
 
     # ---- expert buffers (distill.py:255-283)
     if args.synthetic_experts:
@@ -246,6 +349,9 @@ def main(args):
     first_step = True
     t_start = time.time()
     for it in range(args.Iteration + 1):
+        # ---- evaluation block (distill.py:293-357), when a held-out set was supplied
+        if eval_set is not None and it in eval_it_pool and rank == 0:
+            run_evaluation(args, it, image_syn, text_syn, lr[0].item(), eval_set, eval_eng_box, variant, d_txt, device)
         # ---- expert rotation (distill.py:450-465) and trajectory segment (:466-470)
         e_idx = expert_idx
         expert_idx += 1
@@ -291,13 +397,15 @@ def main(args):
             out["image_syn"].copy_(gi), out["text_syn"].copy_(gt_)
             out["lr"].copy_(torch.stack([gli, glt]))
             losses = torch.stack([grand.detach(), il.detach(), tl.detach()] + ces)
-        if world > 1 and not mode_b:
-            dist.all_reduce(grads)
-            grads.div_(world)
-        # NaN -> leave the loop (distill.py:599-600); one host sync per iteration
+        # NaN -> leave the loop (distill.py:599-600).  The decision is COLLECTIVE: the flag rides in the
+        # all-reduced buffer, so every rank sees the same value, breaks at the same iteration (a rank that
+        # left alone would pair its barrier with the others' next all-reduce) and nobody applies gradients
+        # that another rank's NaN poisoned.  One host sync per iteration.
+        stop = par.reduce_gradients_and_stop_flag_(flat, views, losses[:3], reduce=world > 1 and not mode_b)
         lh = losses[:3].tolist()
-        if math.isnan(lh[1]):
-            print("img_param_loss is NaN at iteration %d: stopping (reference distill.py:599)" % it)
+        if stop:
+            print("img_param_loss is NaN at iteration %d%s: stopping (reference distill.py:599)"
+                  % (it, "" if math.isnan(lh[1]) else " on another rank"))
             break
         # ---- optimizer_lr / optimizer_img / optimizer_txt .step() (distill.py:233-241, 611-613)
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -76,6 +76,7 @@ class UnrollEngine:
             self.lib.mdd_engine_destroy(self.h)
             self.h = None
         self.workspace = None
+        self._ws_view = None      # the view keeps the allocation alive otherwise
 
     def __del__(self):
         try:

@@ -104,11 +104,10 @@ def train_epoch(eng, theta_img, theta_txt, mom_img, mom_txt, images, texts, lr, 
     """One epoch of reference `epoch` (epoch.py:59-98) on (images, texts) with the optimisers of
     evaluate_synset (epoch.py:361-362): SGD(momentum 0.9, weight_decay 5e-4), fixed logit scale 1/0.07,
     shuffled mini-batches; in place on theta_*/mom_*.  Returns (mean loss, first-step flag)."""
-    lib = _lib.load()
+    from .optim import sgd_step
     n = images.shape[0]
     perm = torch.randperm(n, generator=generator).to(images.device)
     loss_sum, seen = 0.0, 0
-    lr_t = torch.tensor([1.0], device=images.device)
     for s in range(0, n - batch + 1, batch):       # the engine's batch is fixed; a ragged tail is dropped
         idx = perm[s:s + batch]
         x = eng.img_forward(0, theta_img, images, idx=idx)
@@ -117,12 +116,8 @@ def train_epoch(eng, theta_img, theta_txt, mom_img, mom_txt, images, texts, lr, 
         loss, xb, yb, _ = eng.contrastive(x, y, LOGIT_SCALE)
         gi = eng.img_backward(0, theta_img, xb)
         gt = eng.txt_backward(0, theta_txt, yb)
-        st = _stream()
         for th, g, m in ((theta_img, gi, mom_img), (theta_txt, gt, mom_txt)):
-            # weight decay: g += wd * theta (torch.optim.SGD), then the momentum step
-            _lib.check(lib.mdd_flat_axpy(_ptr(g), _ptr(g), _ptr(th), _ptr(lr_t), float(weight_decay), th.numel(), st))
-            _lib.check(lib.mdd_flat_sgd_momentum(_ptr(th), _ptr(g), _ptr(m), float(lr), float(momentum),
-                                                 1 if first else 0, th.numel(), st))
+            sgd_step(th, g, m, lr, momentum, weight_decay, first)
         first = False
         loss_sum += float(loss.item()) * batch
         seen += batch

@@ -197,3 +197,24 @@ def synthetic_expert_params(engine, seed, device="cuda"):
             parts.append(0.02 * torch.randn(shape, generator=g))
     tt = torch.cat([t.reshape(-1) for t in parts])
     return ti.to(device), tt.to(device)
+
+
+def student_move_normalised_targets(engine, th0_img, th0_txt, image_syn, text_syn, lr, syn_steps, generator,
+                                    frac=0.1):
+    """Synthetic expert targets theta* = theta0 + sigma * N(0, I) with sigma chosen so that
+    |theta* - theta0| equals the norm of the student's own syn_steps-step move (frac * K * |g0|, g0 = the
+    inner gradient at theta0 on the full synthetic set) -- the construction oracle/gen_golden.py uses.
+    With it the normalised matching loss (reference distill.py:596-597) and the outer gradients depend
+    O(1) on the inner path; a fixed tiny displacement makes grand_loss = 2 regardless of the kernels.
+    Runs the engine's first-order passes in slot 0.  Returns (target_img, target_txt, sigma_img, sigma_txt)."""
+    x0 = engine.img_forward(0, th0_img, image_syn)
+    y0 = engine.txt_forward(0, th0_txt, text_syn)
+    _, xb0, yb0, _ = engine.contrastive(x0, y0, lr[0:1])
+    gi0 = engine.img_backward(0, th0_img, xb0)
+    gt0 = engine.txt_backward(0, th0_txt, yb0)
+    sig_i = float(frac * syn_steps * gi0.norm() / th0_img.numel() ** 0.5)
+    sig_t = float(frac * syn_steps * gt0.norm() / th0_txt.numel() ** 0.5)
+    dev = th0_img.device
+    tgi = th0_img + sig_i * torch.randn(th0_img.shape, device=dev, generator=generator)
+    tgt = th0_txt + sig_t * torch.randn(th0_txt.shape, device=dev, generator=generator)
+    return tgi, tgt, sig_i, sig_t

@@ -9,12 +9,28 @@ import torch.distributed as dist
 
 
 def fused_grad_buffer(image_syn, text_syn):
-    """One flat fp32 buffer with views for the three gradient pieces (a single collective)."""
+    """One flat fp32 buffer [d image_syn | d text_syn | d lr (2) | NaN flag] with views for the pieces:
+    a single collective per iteration carries the gradients AND the stop decision."""
     n_img, n_txt = image_syn.numel(), text_syn.numel()
-    flat = torch.zeros(n_img + n_txt + 2, dtype=torch.float32, device=image_syn.device)
+    flat = torch.zeros(n_img + n_txt + 3, dtype=torch.float32, device=image_syn.device)
     views = dict(image_syn=flat[:n_img].view_as(image_syn),
-                 text_syn=flat[n_img:n_img + n_txt].view_as(text_syn), lr=flat[n_img + n_txt:])
+                 text_syn=flat[n_img:n_img + n_txt].view_as(text_syn),
+                 lr=flat[n_img + n_txt:n_img + n_txt + 2], nan_flag=flat[n_img + n_txt + 2:],
+                 grads=flat[:n_img + n_txt + 2])
     return flat, views
+
+
+def reduce_gradients_and_stop_flag_(flat, views, losses3, reduce=True, group=None):
+    """Mode A's one exchange per iteration, with the reference's NaN break (distill.py:599-600) made
+    COLLECTIVE: every rank writes [its loss is NaN] into the flag slot of the fused buffer BEFORE the
+    all-reduce and tests the REDUCED flag after it.  All ranks therefore stop at the same iteration (a
+    rank leaving alone would pair its final barrier with the others' next all-reduce: mismatched
+    collectives), and no rank applies a gradient that another rank's NaN poisoned.
+    Returns True when the loop must stop.  One host sync (the flag read)."""
+    views["nan_flag"].copy_(torch.isnan(losses3).any().to(torch.float32).reshape(1))
+    if reduce:
+        average_gradients_(flat, group)
+    return bool(views["nan_flag"].item() > 0)
 
 
 def average_gradients_(flat, group=None):

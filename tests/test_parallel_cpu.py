@@ -39,9 +39,10 @@ def _worker(rank, world, port, out):
         views["image_syn"].copy_(torch.randn(image_syn.shape, generator=g))
         views["text_syn"].copy_(torch.randn(text_syn.shape, generator=g))
         views["lr"].copy_(torch.randn(2, generator=g))
-        par.average_gradients_(flat)
-        state = opt.step(state, flat.clone())
-    out[rank] = dict(state=state, experts=experts, perms=perms, flat=flat.clone())
+        stop = par.reduce_gradients_and_stop_flag_(flat, views, torch.tensor([1.0, 0.5, 0.5]))
+        assert not stop
+        state = opt.step(state, views["grads"].clone())
+    out[rank] = dict(state=state, experts=experts, perms=perms, flat=views["grads"].clone())
     dist.destroy_process_group()
 
 
@@ -60,6 +61,40 @@ def test_two_rank_gradient_averaging_and_identical_updates():
         return torch.cat([torch.randn(6, 3, 8, 8, generator=g).flatten(),
                           torch.randn(6, 5, generator=g).flatten(), torch.randn(2, generator=g)])
     assert torch.allclose(a["flat"], 0.5 * (grad(4) + grad(0)), atol=1e-6)
+
+
+def _worker_nan(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multimodal_dataset_distillation_amd import parallel as par
+    image_syn, text_syn = torch.zeros(2, 3, 4, 4), torch.zeros(2, 5)
+    flat, views = par.fused_grad_buffer(image_syn, text_syn)
+    applied, stopped_at = 0, None
+    for it in range(4):
+        views["grads"].fill_(float(rank + 1))
+        nan_here = rank == 1 and it == 2          # only rank 1's expert diverges, at iteration 2
+        losses = torch.tensor([float("nan")] * 3 if nan_here else [1.0, 0.5, 0.5])
+        if nan_here:
+            views["grads"].fill_(float("nan"))
+        if par.reduce_gradients_and_stop_flag_(flat, views, losses):
+            stopped_at = it
+            break
+        assert torch.isfinite(views["grads"]).all()
+        applied += 1
+    dist.barrier()       # would hang / mismatch if one rank were still inside the loop's all-reduce
+    out[rank] = (applied, stopped_at)
+    dist.destroy_process_group()
+
+
+def test_nan_break_is_collective():
+    """a rank whose own expert yields NaN must not leave the loop alone -- every rank stops at
+    the same iteration and none applies the NaN-poisoned averaged gradient."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_nan, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert out[0] == (2, 2) and out[1] == (2, 2)
 
 
 def _toy_shard(rank, world, base):
