@@ -40,6 +40,7 @@ TRAFFIC_FILES = ["traffic_r02.json", "traffic_r01.json"]      # newest first
 # Budget for the post-timing self-check: relative error of the benched mode's outer gradients against ONE
 # f32-mode (exact-fp32 MFMA) iteration on the same inputs.  ~2x the errors measured on MI355X.
 SELFCHECK_BUDGET = {"bf16": dict(grand=5e-3, g_img=1e-1, g_txt=6e-2, g_lr=2e-2),
+                    "bf16x2": dict(grand=1e-4, g_img=1e-3, g_txt=1e-3, g_lr=1e-3),
                     "f32": dict(grand=1e-5, g_img=1e-4, g_txt=1e-4, g_lr=1e-4)}
 
 
@@ -98,7 +99,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "bf16x2", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-launches", default=None,
@@ -254,7 +255,7 @@ def main():
         if flops_iter:
             result["algorithmic_tflops_per_iter"] = flops_iter / 1e12
             result["mfma_util_pct"] = 100.0 * flops_iter * value / world / (
-                (PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS) * 1e12)
+                (PEAK_F32_TFLOPS if args.dtype == "f32" else PEAK_BF16_TFLOPS) * 1e12)
 
     # ---- roofline of the dominant kernel: one extra, HIP-event-instrumented iteration (rank 0)
     if not args.no_roofline:
@@ -277,7 +278,7 @@ def main():
         # dominant kernel class = most time per iteration.  Its roofline is the one its ALGORITHMIC
         # arithmetic intensity selects: below the ridge (peak flops / peak HBM bytes) it is HBM-bound.
         dom = max(kinds, key=lambda d: d["ms"])
-        peak_tf = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        peak_tf = PEAK_F32_TFLOPS if args.dtype == "f32" else PEAK_BF16_TFLOPS   # bf16x2 issues bf16 MFMAs
         secs = dom["ms"] * 1e-3
         tfs = dom["flops"] / secs / 1e12 if secs > 0 else 0.0
         gbs = dom["bytes"] / secs / 1e9 if secs > 0 else 0.0

@@ -39,6 +39,11 @@ extern "C" {
 
 #define MDD_DTYPE_F32 0  /* fp32 storage + exact-fp32 MFMA (parity mode)                    */
 #define MDD_DTYPE_BF16 1 /* bf16 activations/weights, bf16 MFMA, fp32 accumulate, fp32 theta */
+#define MDD_DTYPE_BF16X2 2 /* fp32 storage; every contraction operand split into hi+lo bf16 (16
+                              significand bits), bf16 MFMA with fp32 accumulate: the fast mode that
+                              meets the 1e-3 parity bar                        */
+#define MDD_DTYPE_F32_BF16OPS 3 /* experiment: fp32 storage, operands rounded to ONE bf16 (hi only):
+                                   separates stash rounding from MFMA operand rounding            */
 
 typedef struct mdd_engine mdd_engine;
 

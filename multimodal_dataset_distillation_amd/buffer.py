@@ -63,7 +63,7 @@ def build_parser():
     # additive
     p.add_argument("--synthetic_data", type=int, default=0, metavar="STEPS_PER_EPOCH",
                    help="train on random pairs, this many steps per epoch (no dataset offline)")
-    p.add_argument("--compute_dtype", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--compute_dtype", default="bf16", choices=["bf16", "bf16x2", "f32"])
     p.add_argument("--seed", type=int, default=0)
     return p
 

@@ -47,6 +47,7 @@ template <class AT> struct Mma;
 template <> struct Mma<bf16> {
   static constexpr int KE = 64;  // K elements per 128-byte row
   static constexpr int CE = 8;   // elements per 16-byte chunk
+  static DEVI u32x4 stage(const u32x4& raw, bool) { return raw; }
   static DEVI void step(const u32x4& a, const u32x4& b, f32x16& acc) {
     bf16x8 av = __builtin_bit_cast(bf16x8, a), bv = __builtin_bit_cast(bf16x8, b);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
@@ -55,6 +56,7 @@ template <> struct Mma<bf16> {
 template <> struct Mma<float> {
   static constexpr int KE = 32;
   static constexpr int CE = 4;
+  static DEVI u32x4 stage(const u32x4& raw, bool) { return raw; }
   static DEVI void step(const u32x4& a, const u32x4& b, f32x16& acc) {
     // lane-half h holds k = 4*(2q+h)+j, j=0..3 for BOTH operands: any k-permutation that is the
     // same for A and B leaves the sum unchanged.
@@ -64,6 +66,44 @@ template <> struct Mma<float> {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[3]), __uint_as_float(b[3]), acc, 0, 0, 0);
   }
 };
+
+// Split-bf16 ("bf16x2") math on fp32 storage: every fp32 operand x is carried as hi = bf16(x) and
+// lo = bf16(x - hi) (16 significand bits together, error ~2^-17 per operand instead of 2^-9), and the
+// product is formed by bf16 MFMAs with fp32 accumulation:  x*y ~= xh*yh + xh*yl + xl*yh + xl*yl.
+// The split happens ONCE per element, between the global load and the LDS store; a 16-byte LDS chunk
+// holds [h0 h1 h2 h3 | l0 l1 l2 l3] of four consecutive K positions, so one v_mfma_f32_32x32x16_bf16 on
+// the chunks as they stand yields hh + ll and a second one with the halves of B swapped yields hl + lh:
+// two MFMAs per four K positions (the exact-fp32 v_mfma_f32_32x32x2_f32 path needs four at twice the
+// cycles each) and no operand arithmetic inside the K loop.
+struct MmaSplit {
+  static constexpr int KE = 32;
+  static constexpr int CE = 4;
+  static DEVI u32x4 stage(const u32x4& raw, bool hi_only) {
+    float f[4] = {__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]), __uint_as_float(raw[3])};
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bf16 hb = (bf16)f[i];                                   // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+      h[i] = (unsigned)__builtin_bit_cast(unsigned short, hb);
+      float r = f[i] - __uint_as_float(h[i] << 16);           // exact in fp32
+      bf16 lb = (bf16)r;
+      l[i] = hi_only ? 0u : (unsigned)__builtin_bit_cast(unsigned short, lb);
+    }
+    u32x4 o;
+    o[0] = h[0] | (h[1] << 16); o[1] = h[2] | (h[3] << 16);
+    o[2] = l[0] | (l[1] << 16); o[3] = l[2] | (l[3] << 16);
+    return o;
+  }
+  static DEVI void step(const u32x4& a, const u32x4& b, f32x16& acc) {
+    u32x4 bs;
+    bs[0] = b[2]; bs[1] = b[3]; bs[2] = b[0]; bs[3] = b[1];
+    bf16x8 av = __builtin_bit_cast(bf16x8, a);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, bs), acc, 0, 0, 0);
+  }
+};
+template <class AT, int PREC> struct MmaSel { typedef Mma<AT> type; };
+template <> struct MmaSel<float, 1> { typedef MmaSplit type; };
 
 __device__ __attribute__((aligned(16))) const unsigned g_zero_block[64] = {0};
 
@@ -80,11 +120,12 @@ struct KArgs {
   int M, mtiles, ntiles, dbg;
 };
 
-template <class AT, int WGM, int WGN, int TM, int TN, int MODE, bool KFULL>
+template <class AT, int WGM, int WGN, int TM, int TN, int MODE, bool KFULL, int PREC>
 __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   constexpr int RA = BM / 32, RB = BN / 32;
-  constexpr int KE = Mma<AT>::KE, CE = Mma<AT>::CE;
+  typedef typename MmaSel<AT, PREC>::type MT;
+  constexpr int KE = MT::KE, CE = MT::CE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NBUF = MDD_SINGLE_BUF ? 1 : 2;   // LDS stages (registers hold the slab in flight)
 
@@ -283,11 +324,12 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  const bool hi_only = PREC == 1 && p.g.prec == 2;   // attribution experiment: fp32 stash, bf16 operands
   auto store_tile = [&](const Stage& S) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < RA; ++i) *(u32x4*)(smem + wrA + i * 4096) = S.ra[i];
+    for (int i = 0; i < RA; ++i) *(u32x4*)(smem + wrA + i * 4096) = MT::stage(S.ra[i], hi_only);
 #pragma unroll
-    for (int i = 0; i < RB; ++i) *(u32x4*)(smem + wrB + i * 4096) = S.rb[i];
+    for (int i = 0; i < RB; ++i) *(u32x4*)(smem + wrB + i * 4096) = MT::stage(S.rb[i], hi_only);
     wrA ^= ABUF; wrB ^= BBUF;
   };
   auto compute = [&]() __attribute__((always_inline)) {
@@ -312,7 +354,7 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) Mma<AT>::step(af[q & 1][i], bf[q & 1][j], acc[i][j]);
+        for (int j = 0; j < TN; ++j) MT::step(af[q & 1][i], bf[q & 1][j], acc[i][j]);
       __builtin_amdgcn_sched_barrier(0);
     }
     } else {
@@ -326,7 +368,7 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) Mma<AT>::step(af[i], bf[j], acc[i][j]);
+        for (int j = 0; j < TN; ++j) MT::step(af[i], bf[j], acc[i][j]);
     }
     }
 #pragma unroll
@@ -498,7 +540,7 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
 }
 
 
-template <class AT, int WGM, int WGN, int TM, int TN, int MODE, bool KFULL>
+template <class AT, int WGM, int WGN, int TM, int TN, int MODE, bool KFULL, int PREC>
 void launch_cfg(const KArgs& a, hipStream_t st) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   KArgs k = a;
@@ -514,12 +556,12 @@ void launch_cfg(const KArgs& a, hipStream_t st) {
   (void)hipGetDevice(&dev);
   const uint64_t bit = 1ull << (dev & 63);
   if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_conv_gemm<AT, WGM, WGN, TM, TN, MODE, KFULL>,
+    hipError_t e = hipFuncSetAttribute((const void*)k_conv_gemm<AT, WGM, WGN, TM, TN, MODE, KFULL, PREC>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e == hipSuccess) attr_devs.fetch_or(bit, std::memory_order_release);
   }
   int64_t blocks = (int64_t)k.mtiles * k.ntiles * a.g.groups;
-  k_conv_gemm<AT, WGM, WGN, TM, TN, MODE, KFULL><<<(unsigned)blocks, 256, shm, st>>>(k);
+  k_conv_gemm<AT, WGM, WGN, TM, TN, MODE, KFULL, PREC><<<(unsigned)blocks, 256, shm, st>>>(k);
 }
 
 }  // namespace
@@ -545,14 +587,21 @@ void launch_conv_gemm(const ConvGeom& g, const AT* A1, const AT* B1, const AT* A
   const bool s2t = g.transposed && g.stride == 2;
   const int mode = pw ? 0 : (s2t ? (((g.ho | g.wo) & 1) == 0 && g.k <= 3 ? 2 : 3) : 1);
   const bool kfull = ((g.k * g.k * g.kc) % Mma<AT>::KE) == 0;
+#define MDD_DISPATCH_P(WGM, WGN, TM, TN, PREC)                                                \
+  do {                                                                                        \
+    if (mode == 0) { if (kfull) launch_cfg<AT, WGM, WGN, TM, TN, 0, true, PREC>(a, st);      \
+                     else launch_cfg<AT, WGM, WGN, TM, TN, 0, false, PREC>(a, st); }         \
+    else if (mode == 1) { if (kfull) launch_cfg<AT, WGM, WGN, TM, TN, 1, true, PREC>(a, st); \
+                          else launch_cfg<AT, WGM, WGN, TM, TN, 1, false, PREC>(a, st); }    \
+    else if (mode == 2) launch_cfg<AT, WGM, WGN, TM, TN, 2, false, PREC>(a, st);             \
+    else launch_cfg<AT, WGM, WGN, TM, TN, 3, false, PREC>(a, st);                            \
+  } while (0)
 #define MDD_DISPATCH(WGM, WGN, TM, TN)                                                        \
   do {                                                                                        \
-    if (mode == 0) { if (kfull) launch_cfg<AT, WGM, WGN, TM, TN, 0, true>(a, st);            \
-                     else launch_cfg<AT, WGM, WGN, TM, TN, 0, false>(a, st); }               \
-    else if (mode == 1) { if (kfull) launch_cfg<AT, WGM, WGN, TM, TN, 1, true>(a, st);       \
-                          else launch_cfg<AT, WGM, WGN, TM, TN, 1, false>(a, st); }          \
-    else if (mode == 2) launch_cfg<AT, WGM, WGN, TM, TN, 2, false>(a, st);                   \
-    else launch_cfg<AT, WGM, WGN, TM, TN, 3, false>(a, st);                                  \
+    if constexpr (sizeof(AT) == 4) {                                                          \
+      if (g.prec != 0) { MDD_DISPATCH_P(WGM, WGN, TM, TN, 1); break; }                        \
+    }                                                                                         \
+    MDD_DISPATCH_P(WGM, WGN, TM, TN, 0);                                                      \
   } while (0)
   if (g.nc <= 32) MDD_DISPATCH(4, 1, 1, 1);        // 128 x 32  (stem)
   else if (g.nc <= 64) MDD_DISPATCH(4, 1, 2, 2);   // 256 x 64  (group width 64)
@@ -564,6 +613,7 @@ void launch_conv_gemm(const ConvGeom& g, const AT* A1, const AT* B1, const AT* A
   else MDD_DISPATCH(2, 2, 1, 2);                   // 64 x 128
 #endif
 #undef MDD_DISPATCH
+#undef MDD_DISPATCH_P
 }
 template void launch_conv_gemm<float>(const ConvGeom&, const float*, const float*, const float*,
                                       const float*, const ConvEpi&, hipStream_t);

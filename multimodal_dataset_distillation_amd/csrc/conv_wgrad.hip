@@ -48,10 +48,16 @@ template <int ROWB> DEVI int wswz(int row) { return ROWB == 128 ? ((row >> 1) & 
 
 // PW: pointwise (1x1, stride 1, no padding) instance -- no gather state, no per-step pixel decode
 // PF2: two tiles in flight in staging registers (loads issued two K-steps before their LDS store)
-template <class AT, int BCO, int BKP, int BKM, bool PW, bool PF2>
+// SPLIT (fp32 storage only): split-bf16 math -- each fp32 element is split into hi = bf16(x) and
+// lo = bf16(x - hi) between the global load and the LDS store, into two bf16 planes with the bf16 path's
+// layout; the contraction is hh + hl + lh on v_mfma_f32_16x16x32_bf16 (the ll term is below 2^-16 relative).
+template <class AT, int BCO, int BKP, int BKM, bool PW, bool PF2, bool SPLIT>
 __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArgs p) {
   constexpr int CE = 16 / (int)sizeof(AT);
   constexpr bool BF = sizeof(AT) == 2;
+  constexpr bool TR = BF || SPLIT;                       // fragments by ds_read_b64_tr_b16 from bf16 planes
+  constexpr int TD = BCO * 2, TX = BKP * 2;              // bf16 plane row bytes
+  static_assert(!SPLIT || sizeof(AT) == 4, "split-bf16 math is a mode of the fp32-storage engine");
   constexpr int DCH = BCO / CE, XCH = BKP / CE;          // chunks per row
   constexpr int DROWB = BCO * sizeof(AT), XROWB = BKP * sizeof(AT);
   constexpr int DSL = (BKM * DCH) / 256, XSL = (BKM * XCH) / 256;   // chunks per thread
@@ -60,7 +66,7 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
   constexpr int WCO = BCO / 64, WKP = 4 / WCO;           // wave grid over (co, k')
   constexpr int WKW = BKP / WKP;                         // k' width per wave
   static_assert(DSL >= 1 && XSL >= 1, "tile too small for 256 threads");
-  static_assert(BF || (BCO == 64 && BKP == 128), "f32 path: 64x128 tile only");
+  static_assert(TR || (BCO == 64 && BKP == 128), "f32 path: 64x128 tile only");
   constexpr int NBUF = MDD_WG_SINGLE_BUF ? 1 : 2;   // LDS stages (registers hold the tile in flight)
   __shared__ __attribute__((aligned(16))) char smem[NBUF * (DTILE + XTILE)];
   char* Ds = smem;
@@ -150,6 +156,7 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
 #pragma unroll
   for (int e = 0; e < CE; ++e) bsum[e] = 0.f;
   const bool do_bias = p.dbias != nullptr && kpt == 0;
+  const bool hi_only = SPLIT && p.g.prec == 2;   // attribution experiment: bf16 operands from an fp32 stash
 
   auto load_tile = [&](auto SI, int it) {
     constexpr int si = decltype(SI)::value;
@@ -192,11 +199,29 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
     const bool bias_now = biasS[si];
     char* d = Ds + buf * DTILE;
     char* x = Xs + buf * XTILE;
+    auto split_store = [&](char* plane_hi, int plane_bytes, int row_bytes, int r, int unit, const u32x4& raw) {
+      unsigned h[4], l[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float f = __uint_as_float(raw[e]);
+        bf16 hb = (bf16)f;
+        h[e] = (unsigned)__builtin_bit_cast(unsigned short, hb);
+        bf16 lb = (bf16)(f - __uint_as_float(h[e] << 16));
+        l[e] = hi_only ? 0u : (unsigned)__builtin_bit_cast(unsigned short, lb);
+      }
+      char* a = plane_hi + r * row_bytes + unit * 8;
+      *(uint2*)a = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+      *(uint2*)(a + plane_bytes) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+    };
 #pragma unroll
     for (int i = 0; i < DSL; ++i) {
       int r = drow + DSTEP * i;
-      int c = BF ? (dcol ^ (wswz<DROWB>(r) << 1)) : dcol;
-      *(u32x4*)(d + r * DROWB + c * 16) = rd[i];
+      if constexpr (SPLIT) {
+        split_store(d, BKM * TD, TD, r, dcol ^ (wswz<TD>(r) << 2), rd[i]);
+      } else {
+        int c = BF ? (dcol ^ (wswz<DROWB>(r) << 1)) : dcol;
+        *(u32x4*)(d + r * DROWB + c * 16) = rd[i];
+      }
       if (bias_now) {
         float f[CE];
         Chunk<AT>::unpack(__builtin_bit_cast(uint4, rd[i]), f);
@@ -207,14 +232,18 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
 #pragma unroll
     for (int i = 0; i < XSL; ++i) {
       int r = xrow + XSTEP * i;
-      int c = BF ? (xcol ^ (wswz<XROWB>(r) << 1)) : xcol;
-      *(u32x4*)(x + r * XROWB + c * 16) = rx[i];
+      if constexpr (SPLIT) {
+        split_store(x, BKM * TX, TX, r, xcol ^ (wswz<TX>(r) << 2), rx[i]);
+      } else {
+        int c = BF ? (xcol ^ (wswz<XROWB>(r) << 1)) : xcol;
+        *(u32x4*)(x + r * XROWB + c * 16) = rx[i];
+      }
     }
   };
 
   // accumulators: f32 -> 2 blocks of 32x32 (co 0..31, 32..63) x (32 k' of this wave)
   //               bf16 -> 4 x (WKW/16) blocks of 16x16 (64 co x WKW k' per wave)
-  constexpr int NBK = BF ? WKW / 16 : 1;
+  constexpr int NBK = TR ? WKW / 16 : 1;
   f32x16 accf[2];
   f32x4 accb[4][NBK];
 #pragma unroll
@@ -244,7 +273,45 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
     else { if (it + 1 < niter) load_tile(SN, it + 1); }
     const char* d = Ds + buf * DTILE;
     const char* x = Xs + buf * XTILE;
-    if constexpr (!BF) {
+    if constexpr (SPLIT) {
+      const int gq = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+      typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+#pragma unroll
+      for (int ks = 0; ks < BKM / 32; ++ks) {
+        s16x4 ah[4][2], al[4][2], bh[NBK][2], bl[NBK][2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          int row = ks * 32 + 4 * (2 * (2 * e + (gq >> 1)) + (gq & 1)) + q;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            int unit = (wc * 64 + 16 * i + 4 * pp) >> 2;
+            const char* a = d + row * TD + (unit ^ (wswz<TD>(row) << 2)) * 8;
+            ah[i][e] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)a);
+            al[i][e] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a + BKM * TD));
+          }
+#pragma unroll
+          for (int j = 0; j < NBK; ++j) {
+            int unit = (wk * WKW + 16 * j + 4 * pp) >> 2;
+            const char* a = x + row * TX + (unit ^ (wswz<TX>(row) << 2)) * 8;
+            bh[j][e] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)a);
+            bl[j][e] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a + BKM * TX));
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NBK; ++j) {
+            bf16x8 a8h = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(ah[i][0], ah[i][1], 0, 1, 2, 3, 4, 5, 6, 7));
+            bf16x8 a8l = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(al[i][0], al[i][1], 0, 1, 2, 3, 4, 5, 6, 7));
+            bf16x8 b8h = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(bh[j][0], bh[j][1], 0, 1, 2, 3, 4, 5, 6, 7));
+            bf16x8 b8l = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(bl[j][0], bl[j][1], 0, 1, 2, 3, 4, 5, 6, 7));
+            accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8h, b8h, accb[i][j], 0, 0, 0);
+            accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8h, b8l, accb[i][j], 0, 0, 0);
+            accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8l, b8h, accb[i][j], 0, 0, 0);
+          }
+      }
+    } else if constexpr (!BF) {
       const int l31 = lane & 31, lh = lane >> 5;
 #pragma unroll
       for (int t = 0; t < BKM / 2; ++t) {
@@ -307,7 +374,7 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
   if (MDD_DBG_BITS(p) & 2) return;   // dbg bit1: no write-out (timing only)
   // ---- write-out: fp32 atomics into dW[g][co][k']
   float* dWg = p.dW + (size_t)grp * G.nc * ktot;
-  if constexpr (!BF) {
+  if constexpr (!TR) {
     const int l31 = lane & 31, lh = lane >> 5;
     int kcol = kp0 + wk * 32 + l31;
     if (kcol < ktot) {
@@ -391,8 +458,15 @@ void launch_cfg(WArgs a, hipStream_t st) {
 #endif
   dim3 grid(tiles, splits);
   constexpr bool PF2 = MDD_WG_PF2 && sizeof(AT) == 2 && BCO == 128;   // 2 waves/SIMD either way there
-  if (pw) k_conv_wgrad<AT, BCO, BKP, BKM, true, PF2><<<grid, 256, 0, st>>>(a);
-  else k_conv_wgrad<AT, BCO, BKP, BKM, false, false><<<grid, 256, 0, st>>>(a);
+  if constexpr (sizeof(AT) == 4) {
+    if (g.prec != 0) {
+      if (pw) k_conv_wgrad<AT, BCO, BKP, BKM, true, false, true><<<grid, 256, 0, st>>>(a);
+      else k_conv_wgrad<AT, BCO, BKP, BKM, false, false, true><<<grid, 256, 0, st>>>(a);
+      return;
+    }
+  }
+  if (pw) k_conv_wgrad<AT, BCO, BKP, BKM, true, PF2, false><<<grid, 256, 0, st>>>(a);
+  else k_conv_wgrad<AT, BCO, BKP, BKM, false, false, false><<<grid, 256, 0, st>>>(a);
 }
 
 }  // namespace

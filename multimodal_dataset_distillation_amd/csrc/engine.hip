@@ -146,6 +146,7 @@ namespace {
 template <class AT>
 struct Eng : mdd_engine {
   NfCfg nf;
+  int prec = 0;   // ConvGeom::prec of every contraction (fp32 storage: 0 exact, 1 split-bf16, 2 hi only)
   int N, S, Dt, K;
   std::vector<ConvL> convs;
   std::vector<Blk> blks;
@@ -430,13 +431,13 @@ struct Eng : mdd_engine {
     ConvGeom g; g.nimg = N; g.ha = L.hin; g.wa = L.hin; g.ca_tot = L.cin_pad;
     g.ho = L.hout; g.wo = L.hout; g.co_tot = L.cout; g.kc = L.cin_pad / L.groups;
     g.nc = L.cout / L.groups; g.groups = L.groups; g.k = L.k; g.stride = L.stride; g.pad = L.pad;
-    g.transposed = 0; return g;
+    g.transposed = 0; g.prec = prec; return g;
   }
   ConvGeom gdgrad(const ConvL& L) const {
     ConvGeom g; g.nimg = N; g.ha = L.hout; g.wa = L.hout; g.ca_tot = L.cout;
     g.ho = L.hin; g.wo = L.hin; g.co_tot = L.cin_pad; g.kc = L.cout / L.groups;
     g.nc = L.cin_pad / L.groups; g.groups = L.groups; g.k = L.k; g.stride = L.stride; g.pad = L.pad;
-    g.transposed = 1; return g;
+    g.transposed = 1; g.prec = prec; return g;
   }
 
   // ---- side stream: weight-gradient contractions only depend on (dy, x) of their own layer, so
@@ -962,6 +963,12 @@ int mdd_engine_create(const mdd_config* cfg, mdd_engine** out) {
     int rc = e->build(*cfg);
     if (rc) { delete e; return rc; }
     *out = e;
+  } else if (cfg->dtype == MDD_DTYPE_BF16X2 || cfg->dtype == MDD_DTYPE_F32_BF16OPS) {
+    auto* e = new Eng<float>();
+    e->prec = cfg->dtype == MDD_DTYPE_BF16X2 ? 1 : 2;
+    int rc = e->build(*cfg);
+    if (rc) { delete e; return rc; }
+    *out = e;
   } else {
     return mdd_set_error_msg(2, "mdd: invalid argument: dtype");
   }
@@ -1141,11 +1148,14 @@ int mdd_op_conv2d(int dtype, int transposed, int nimg, int hin, int win, int cin
                   int stride, int pad, int groups, const void* a, const void* w, const float* bias,
                   void* out, void* stream) {
   CHECK_ARG(a && w && out, "null pointer");
+  CHECK_ARG(dtype >= 0 && dtype <= 3, "dtype");
   CHECK_ARG(stride == 1 || stride == 2, "stride must be 1 or 2");
   ConvGeom g = op_geom(transposed, nimg, hin, win, cin, cout, k, stride, pad, groups);
   ConvEpi e; memset(&e, 0, sizeof e);
   e.mode = transposed ? EPI_BWD_LIN : EPI_FWD; e.bias = bias; e.out_raw = out; e.beta = 1.f;
-  if (dtype == MDD_DTYPE_F32)
+  if (dtype == MDD_DTYPE_BF16X2) g.prec = 1;
+  if (dtype == MDD_DTYPE_F32_BF16OPS) g.prec = 2;
+  if (dtype != MDD_DTYPE_BF16)
     launch_conv_gemm<float>(g, (const float*)a, (const float*)w, nullptr, nullptr, e, (hipStream_t)stream);
   else
     launch_conv_gemm<bf16>(g, (const bf16*)a, (const bf16*)w, nullptr, nullptr, e, (hipStream_t)stream);
@@ -1156,8 +1166,11 @@ int mdd_op_conv2d_wgrad(int dtype, int nimg, int hin, int win, int cin, int cout
                         int pad, int groups, const void* dy, const void* x, float* dw, float* db,
                         void* stream) {
   CHECK_ARG(dy && x && dw, "null pointer");
+  CHECK_ARG(dtype >= 0 && dtype <= 3, "dtype");
   ConvGeom g = op_geom(0, nimg, hin, win, cin, cout, k, stride, pad, groups);
-  if (dtype == MDD_DTYPE_F32)
+  if (dtype == MDD_DTYPE_BF16X2) g.prec = 1;
+  if (dtype == MDD_DTYPE_F32_BF16OPS) g.prec = 2;
+  if (dtype != MDD_DTYPE_BF16)
     launch_conv_wgrad<float>(g, (const float*)dy, (const float*)x, nullptr, nullptr, dw, db, (hipStream_t)stream);
   else
     launch_conv_wgrad<bf16>(g, (const bf16*)dy, (const bf16*)x, nullptr, nullptr, dw, db, (hipStream_t)stream);

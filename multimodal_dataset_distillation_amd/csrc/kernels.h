@@ -79,6 +79,7 @@ struct ConvGeom {
   int groups;
   int k, stride, pad;     // conv kernel size / stride / padding (of the FORWARD conv)
   int transposed;         // 0: forward gather, 1: dgrad gather
+  int prec = 0;           // fp32 storage only: 0 exact-fp32 MFMA, 1 split-bf16 (hi+lo) MFMA, 2 hi only
 };
 template <class AT>
 void launch_conv_gemm(const ConvGeom& g, const AT* A1, const AT* B1, const AT* A2, const AT* B2,

@@ -100,7 +100,7 @@ def build_parser():
     p.add_argument("--engine", default="fused", choices=["fused", "autograd"],
                    help="fused: one C-ABI call per iteration; autograd: the reference loop verbatim "
                         "through ReparamModule + torch.autograd over the HIP ops")
-    p.add_argument("--compute_dtype", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--compute_dtype", default="bf16", choices=["bf16", "bf16x2", "f32"])
     p.add_argument("--pix_init", default="noise", choices=["noise", "real"])   # distill_original.py:138
     p.add_argument("--txt_init", default="noise", choices=["noise", "real"])   # distill_original.py:146
     p.add_argument("--logit_scale", type=float, default=None,

@@ -11,10 +11,13 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import DTYPE_BF16, DTYPE_F32, MddConfig, MddIterArgs, check
+from ._lib import DTYPE_BF16, DTYPE_BF16X2, DTYPE_F32, DTYPE_F32_BF16OPS, MddConfig, MddIterArgs, check
 
+# f32: exact-fp32 MFMA; bf16: bf16 storage + MFMA; bf16x2: fp32 storage, split hi+lo bf16 operands (the
+# fast mode within the 1e-3 parity bar); f32_bf16ops: experiment (fp32 storage, single-bf16 operands)
 _DT = {"f32": DTYPE_F32, "fp32": DTYPE_F32, "float32": DTYPE_F32, "bf16": DTYPE_BF16,
-       "bfloat16": DTYPE_BF16}
+       "bfloat16": DTYPE_BF16, "bf16x2": DTYPE_BF16X2, "f32_bf16ops": DTYPE_F32_BF16OPS}
+FP32_STORAGE = ("f32", "fp32", "float32", "bf16x2", "f32_bf16ops")
 
 
 def _ptr(t):
@@ -103,7 +106,7 @@ class UnrollEngine:
         off, elems, isf = C.c_int64(), C.c_int64(), C.c_int()
         check(self.lib.mdd_engine_find_buffer(self.h, name.encode(), slot, C.byref(off),
                                               C.byref(elems), C.byref(isf)))
-        esz = 4 if (isf.value or self.dtype in ("f32", "fp32", "float32")) else 2
+        esz = 4 if (isf.value or self.dtype in FP32_STORAGE) else 2
         raw = self._ws_view[off.value: off.value + elems.value * esz]
         if isf.value or esz == 4:
             return raw.view(torch.float32)

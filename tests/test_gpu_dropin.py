@@ -96,7 +96,13 @@ def test_text_only_golden_through_hip_ops(report):
     eng.close()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+# bf16 budgets at C1: ~2x the measured errors (round 1: grand 1.3e-3, g_img_slice 4.1e-2, g_txt 2.1e-2,
+# g_lri 2.8e-3).  f32_bf16ops is the attribution experiment (fp32 stash, single-bf16 MFMA operands).
+BF16_C1 = dict(grand=3e-3, img_loss=3e-3, ces=1e-3, g_img_slice=8e-2, g_img_norm=4e-2, g_txt=4.5e-2,
+               g_lri=6e-3, g_lrt=6e-3)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16x2", "bf16", "f32_bf16ops"])
 def test_config1_golden_scalars(dtype, report):
     """BASELINE configs[0]: N=10, syn_steps=2, NFNet-l0 + 768-d text, 224x224.  theta0 / targets are
     regenerated from the golden's seeds with the oracle constructors (torch CPU RNG)."""
@@ -131,8 +137,10 @@ def test_config1_golden_scalars(dtype, report):
              g_lri=abs(out["lr"][0].item() - g["it0_g_lr_img"]) / abs(g["it0_g_lr_img"]),
              g_lrt=abs(out["lr"][1].item() - g["it0_g_lr_txt"]) / abs(g["it0_g_lr_txt"]))
     report(f"config-1 golden scalars {dtype}: " + " ".join(f"{k} {float(v):.2e}" for k, v in e.items()))
-    tol = 1e-3 if dtype == "f32" else 1e-1
-    assert all(float(v) < tol for v in e.values()), e
+    if dtype in ("f32", "bf16x2"):
+        assert all(float(v) < 1e-3 for v in e.values()), e
+    else:
+        assert all(float(e[k]) < BF16_C1[k] for k in e), e
     eng.close()
 
 

@@ -13,7 +13,9 @@ from conftest import GOLDEN, rel_err
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"f32": 1e-3, "bf16": 1e-1}
+# f32 / bf16x2: the north_star bar.  bf16: ~2x the errors measured on MI355X for these miniature cases
+# (single-bf16 operands through two derivative orders; gpurun_out/test_report.txt)
+TOL = {"f32": 1e-3, "bf16x2": 1e-3, "bf16": 6e-2}
 
 
 def make_oracle(variant, d_txt, seed):
@@ -28,7 +30,7 @@ def make_oracle(variant, d_txt, seed):
     return dr.FlatModule(enc), dr.FlatModule(head)
 
 
-@pytest.fixture(scope="module", params=["f32", "bf16"])
+@pytest.fixture(scope="module", params=["f32", "bf16x2", "bf16"])
 def setup(request):
     from multimodal_dataset_distillation_amd.engine import UnrollEngine
     from oracle import distill_ref as dr
@@ -39,6 +41,9 @@ def setup(request):
                        syn_steps=2, dtype=dtype)
     img, txt = dr.synthetic_inputs(n, size, d_txt, seed=5)
     return dict(eng=eng, fi=fi, ft=ft, img=img, txt=txt, n=n, dtype=dtype)
+
+
+BF16_TINY_IT1 = 0.3   # iteration 1 of the tiny golden in bf16 (pixels ~5e2 after one lr=1000 step): ~2x measured
 
 
 def test_param_table_matches_oracle(setup):
@@ -205,7 +210,7 @@ def test_text_and_loss_passes(setup, report):
     assert max(e0, e1, e2, e3, e4, e5, e6) < tol
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16x2", "bf16"])
 def test_unrolled_match_golden_tiny(dtype, report):
     """tests/golden/unroll_tiny.npz: two consecutive outer iterations incl. SGD momentum."""
     from multimodal_dataset_distillation_amd import _lib
@@ -240,7 +245,7 @@ def test_unrolled_match_golden_tiny(dtype, report):
         report(f"unrolled_match golden tiny {dtype} it{it}: " + " ".join(f"{k} {float(v):.2e}" for k, v in e.items()))
         # bf16: iteration 1 starts from pixels of magnitude ~5e2 (one lr=1000 step on a toy net);
         # operand rounding then dominates d/d(image) -- reported, bounded loosely.
-        tol_it = tol if (dtype == "f32" or it == 0) else 0.5
+        tol_it = tol if (dtype != "bf16" or it == 0) else BF16_TINY_IT1
         assert all(float(v) < tol_it for v in e.values()), e
         # the three SGD(momentum=0.5) steps (distill.py:233-241, 611-613) through the C ABI
         for p, gr, b, lrv in ((image_syn, out["image_syn"], bufs[0], 1000.0),
