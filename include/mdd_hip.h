@@ -55,6 +55,12 @@ typedef struct mdd_config {
   int32_t d_txt;       /* text embedding dim (768 for BERT, networks.py:824)               */
   int32_t syn_steps;   /* number of activation stashes kept (unroll depth)                 */
   int32_t dtype;       /* MDD_DTYPE_*                                                      */
+  int32_t keep_steps;  /* activation stash policy of mdd_unrolled_match: the first keep_steps inner
+                          steps keep their forward/backward activations in HBM for the reverse sweep;
+                          the others share ONE stash slot and are recomputed (forward + inner
+                          gradient at the kept theta_k) when the sweep reaches them.  < 0 or
+                          >= syn_steps: keep every step (no recompute).  Workspace shrinks from
+                          syn_steps+1 to keep_steps+2 activation sets.              */
 } mdd_config;
 
 const char* mdd_last_error(void);

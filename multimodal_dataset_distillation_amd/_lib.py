@@ -15,7 +15,7 @@ DTYPE_F32, DTYPE_BF16, DTYPE_BF16X2, DTYPE_F32_BF16OPS = 0, 1, 2, 3
 class MddConfig(C.Structure):
     _fields_ = [("variant", C.c_char_p), ("batch", C.c_int32), ("num_queries", C.c_int32),
                 ("image_size", C.c_int32), ("d_txt", C.c_int32), ("syn_steps", C.c_int32),
-                ("dtype", C.c_int32)]
+                ("dtype", C.c_int32), ("keep_steps", C.c_int32)]
 
 
 class MddIterArgs(C.Structure):

@@ -148,6 +148,10 @@ struct Eng : mdd_engine {
   NfCfg nf;
   int prec = 0;   // ConvGeom::prec of every contraction (fp32 storage: 0 exact, 1 split-bf16, 2 hi only)
   int N, S, Dt, K;
+  // Activation stash policy: steps k < keep own stash slot k; steps k >= keep share slot
+  // `keep` and are recomputed by the reverse sweep.  nslots = activation sets besides the tangent set.
+  int keep = 0, nslots = 0;
+  int slot_of(int k) const { return k < keep ? k : keep; }
   std::vector<ConvL> convs;
   std::vector<Blk> blks;
   int stem[4], fin;
@@ -214,6 +218,8 @@ struct Eng : mdd_engine {
     CHECK_ARG(N >= 2 && N <= 1024, "batch must be in [2,1024]");
     CHECK_ARG(K >= 1 && K <= 64, "syn_steps must be in [1,64]");
     CHECK_ARG(Dt >= 1, "d_txt");
+    keep = (c.keep_steps < 0 || c.keep_steps >= K) ? K : c.keep_steps;
+    nslots = keep >= K ? K : keep + 1;
     int64_t off = 0;
     auto add_param = [&](std::vector<ParamInfo>& tab, const std::string& name,
                          std::initializer_list<int64_t> shp) {
@@ -378,8 +384,8 @@ struct Eng : mdd_engine {
     for (int i = 0; i < 3; ++i) plan(&lin_mem[i], lin_scratch_bytes(), nullptr, -2);
     plan(&ln_stats, (int64_t)N * 4, nullptr, -2);
     plan(&lossw, loss_work_floats(N, feat), nullptr, -2);
-    sets.resize(K);
-    for (int k = 0; k < K; ++k) plan_set(sets[k], k);
+    sets.resize(nslots);
+    for (int k = 0; k < nslots; ++k) plan_set(sets[k], k);
     plan_set(tn, -1);
     thI.assign(K + 1, nullptr); thT.assign(K + 1, nullptr); gI.assign(K, nullptr); gT.assign(K, nullptr);
     for (int k = 1; k <= K; ++k) { plan(&thI[k], P_img, nullptr, -2); plan(&thT[k], P_txt, nullptr, -2); }
@@ -630,7 +636,7 @@ struct Eng : mdd_engine {
   int img_forward(bool T, int slot, const float* th, const float* th_t, const float* image,
                   const int64_t* idx, float* feat_out, hipStream_t st) override {
     CHECK_ARG(base, "workspace not bound");
-    CHECK_ARG(slot >= 0 && slot < K, "slot out of range");
+    CHECK_ARG(slot >= 0 && slot < nslots, "slot out of range");
     ActSet& P = sets[slot]; ActSet& Q = tn;
     int nb = (int)blks.size();
     launch_ws_forward<AT>(d_descs, (int)descs.size(), total_rows, total_tiles, th, T ? th_t : nullptr, wf, wt,
@@ -696,7 +702,7 @@ struct Eng : mdd_engine {
                    const float* ybar_t_in, float* gout, float* dimage, const int64_t* idx,
                    const float* coef, float mul, bool repack, bool stash, hipStream_t st) override {
     CHECK_ARG(base, "workspace not bound");
-    CHECK_ARG(slot >= 0 && slot < K, "slot out of range");
+    CHECK_ARG(slot >= 0 && slot < nslots, "slot out of range");
     ActSet& P = sets[slot]; ActSet& Q = tn;
     ActSet& O = (!T && !stash) ? tn : P;  // where primal backward signals are written
     int nb = (int)blks.size();
@@ -803,7 +809,7 @@ struct Eng : mdd_engine {
   int txt_forward(bool T, int slot, const float* th, const float* th_t, const float* text,
                   const int64_t* idx, const float* mask, float* feat_out, hipStream_t st) override {
     CHECK_ARG(base, "workspace not bound");
-    CHECK_ARG(slot >= 0 && slot < K, "slot out of range");
+    CHECK_ARG(slot >= 0 && slot < nslots, "slot out of range");
     ActSet& P = sets[slot]; ActSet& Q = tn;
     if (!T) launch_gather_rows(P.tx, text, idx, N, Dt, st);
     auto tt = [&](int64_t o) { return T ? th_t + o : nullptr; };
@@ -822,13 +828,13 @@ struct Eng : mdd_engine {
     POST_WALK("txt_forward");
     return 0;
   }
-  std::vector<const float*> slot_mask_ = std::vector<const float*>(64, nullptr);
+  std::vector<const float*> slot_mask_ = std::vector<const float*>(65, nullptr);
 
   int txt_backward(bool T, int slot, const float* th, const float* th_t, const float* ybar_in,
                    const float* ybar_t_in, float* gout, float* dtext, const int64_t* idx,
                    const float* coef, float mul, bool stash, hipStream_t st) override {
     CHECK_ARG(base, "workspace not bound");
-    CHECK_ARG(slot >= 0 && slot < K, "slot out of range");
+    CHECK_ARG(slot >= 0 && slot < nslots, "slot out of range");
     ActSet& P = sets[slot]; ActSet& Q = tn;
     ActSet& O = (!T && !stash) ? tn : P;
     auto tt = [&](int64_t o) { return T ? th_t + o : nullptr; };
@@ -882,24 +888,33 @@ struct Eng : mdd_engine {
     for (int k = 1; k <= Ks; ++k) { tI[k] = thI[k]; tT[k] = thT[k]; }
     HIP_CHECK_RET(hipMemsetAsync(dsc, 0, 16 * sizeof(double), st));
     // ---- unrolled student training (distill.py:509-583)
-    for (int k = 0; k < Ks; ++k) {
+    // primal forward + contrastive head + inner gradient of step k at theta_k, activations into `slot`
+    auto primal_step = [&](int k, int slot) -> int {
       const int64_t* idx = a->perms ? a->perms + (int64_t)k * N : nullptr;
       const float* mask = a->drop_masks ? a->drop_masks + (int64_t)k * nfeat : nullptr;
+      ActSet& Pk = sets[slot];
       // the text projection runs on its own stream beside the image encoder; they meet at the
       // contrastive head
       fork_to(ts, st);
-      if ((rc = txt_forward(false, k, tT[k], nullptr, a->text_syn, idx, mask, nullptr, ts))) return rc;
-      if ((rc = img_forward(false, k, tI[k], nullptr, a->image_syn, idx, nullptr, st))) return rc;
+      if ((rc = txt_forward(false, slot, tT[k], nullptr, a->text_syn, idx, mask, nullptr, ts))) return rc;
+      if ((rc = img_forward(false, slot, tI[k], nullptr, a->image_syn, idx, nullptr, st))) return rc;
       join_from(ts, st);
-      if ((rc = contrastive(false, sets[k].y, sets[k].ty, nullptr, nullptr, scale_dev,
-                            a->logit_scale_const, a->losses + 3 + k, sets[k].yB, sets[k].tyB, sbar, st)))
+      if ((rc = contrastive(false, Pk.y, Pk.ty, nullptr, nullptr, scale_dev,
+                            a->logit_scale_const, a->losses + 3 + k, Pk.yB, Pk.tyB, sbar, st)))
         return rc;
       fork_to(ts, st);
-      if ((rc = txt_backward(false, k, tT[k], nullptr, sets[k].tyB, nullptr, gT[k], nullptr, nullptr,
+      if ((rc = txt_backward(false, slot, tT[k], nullptr, Pk.tyB, nullptr, gT[k], nullptr, nullptr,
                              nullptr, 0.f, true, ts))) return rc;
-      launch_axpy_out(thT[k + 1], tT[k], gT[k], a->lr_txt, -1.f, P_txt, ts);
-      if ((rc = img_backward(false, k, tI[k], nullptr, sets[k].yB, nullptr, gI[k], nullptr, nullptr,
+      if ((rc = img_backward(false, slot, tI[k], nullptr, Pk.yB, nullptr, gI[k], nullptr, nullptr,
                              nullptr, 0.f, false, true, st))) return rc;
+      return 0;
+    };
+    int shared_holds = -1;   // which step's activations the shared (recompute) slot currently holds
+    for (int k = 0; k < Ks; ++k) {
+      const int slot = slot_of(k);
+      if ((rc = primal_step(k, slot))) return rc;
+      if (slot == keep) shared_holds = k;
+      launch_axpy_out(thT[k + 1], tT[k], gT[k], a->lr_txt, -1.f, P_txt, ts);
       launch_axpy_out(thI[k + 1], tI[k], gI[k], a->lr_img, -1.f, P_img, st);
     }
     join_from(ts, st);
@@ -916,21 +931,30 @@ struct Eng : mdd_engine {
     HIP_CHECK_RET(hipMemsetAsync(a->grad_text_syn, 0, (size_t)cfg.num_queries * Dt * 4, st));
     for (int k = Ks - 1; k >= 0; --k) {
       const int64_t* idx = a->perms ? a->perms + (int64_t)k * N : nullptr;
+      const int slot = slot_of(k);
+      if (slot == keep && keep < K && shared_holds != k) {
+        // stash policy: this step's activations were not kept -- recompute its forward pass and inner
+        // gradient at the kept theta_k into the shared slot (3 of the 12 contractions this step then costs)
+        join_from(ts, st);
+        if ((rc = primal_step(k, slot))) return rc;
+        shared_holds = k;
+      }
+      ActSet& Pk = sets[slot];
       fork_to(ts, st);
       launch_dot(gT[k], lamT, dsc + 5, -1.0, P_txt, ts);
       launch_scale_out(nuT, lamT, a->lr_txt, 1.f, P_txt, ts);
-      if ((rc = txt_forward(true, k, tT[k], nuT, nullptr, nullptr, nullptr, fy_t, ts))) return rc;
+      if ((rc = txt_forward(true, slot, tT[k], nuT, nullptr, nullptr, nullptr, fy_t, ts))) return rc;
       launch_dot(gI[k], lamI, dsc + 4, -1.0, P_img, st);   // d/d lr_img  -= <g_k, lambda>
       launch_scale_out(nuI, lamI, a->lr_img, 1.f, P_img, st);  // direction v = lr * lambda
-      if ((rc = img_forward(true, k, tI[k], nuI, nullptr, nullptr, fx_t, st))) return rc;
+      if ((rc = img_forward(true, slot, tI[k], nuI, nullptr, nullptr, fx_t, st))) return rc;
       join_from(ts, st);
-      if ((rc = contrastive(true, sets[k].y, sets[k].ty, fx_t, fy_t, scale_dev, a->logit_scale_const,
+      if ((rc = contrastive(true, Pk.y, Pk.ty, fx_t, fy_t, scale_dev, a->logit_scale_const,
                             nullptr, xbar_t, ybar_t, sbar_t, st))) return rc;
       fork_to(ts, st);
-      if ((rc = txt_backward(true, k, tT[k], nuT, nullptr, ybar_t, hT, a->grad_text_syn, idx, nullptr,
+      if ((rc = txt_backward(true, slot, tT[k], nuT, nullptr, ybar_t, hT, a->grad_text_syn, idx, nullptr,
                              -1.f, true, ts))) return rc;
       launch_sub_inplace(lamT, hT, P_txt, ts);
-      if ((rc = img_backward(true, k, tI[k], nuI, nullptr, xbar_t, hI, a->grad_image_syn, idx, nullptr,
+      if ((rc = img_backward(true, slot, tI[k], nuI, nullptr, xbar_t, hI, a->grad_image_syn, idx, nullptr,
                              -1.f, false, true, st))) return rc;
       if (a->use_lr_as_scale) launch_accum_f2d(dsc + 4, sbar_t, -1.0, st);
       launch_sub_inplace(lamI, hI, P_img, st);

@@ -111,6 +111,9 @@ def build_parser():
                         "--buffer_path (no dataset/pretrained weights exist offline)")
     p.add_argument("--save_dir", type=str, default=None)
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--keep_steps", type=int, default=None,
+                   help="activation stash policy: keep the activations of the first KEEP inner steps in "
+                        "HBM, recompute the others during the outer backward (default: keep all)")
     p.add_argument("--dist_backend", default="nccl", choices=["nccl", "gloo"],
                    help="torch.distributed backend under a launcher (nccl = RCCL; gloo lets several "
                         "ranks share one GPU in tests)")
@@ -287,7 +290,8 @@ def main(args):
 
     eng = UnrollEngine(variant, batch=batch // world if mode_b else batch, num_queries=args.num_queries,
                        image_size=args.image_size,
-                       d_txt=d_txt, syn_steps=args.syn_steps, dtype=args.compute_dtype, device=device)
+                       d_txt=d_txt, syn_steps=args.syn_steps, dtype=args.compute_dtype, device=device,
+                       keep_steps=args.keep_steps)
     lib = _lib.load()
     from .embed_cache import load_embed_cache, load_eval_data
     # ---- on-disk inputs around the loop (distill.py:221-229): caption-embedding caches

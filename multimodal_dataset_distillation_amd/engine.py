@@ -38,15 +38,19 @@ def _f32(t):
 
 class UnrollEngine:
     def __init__(self, variant="nfnet_l0", batch=100, num_queries=None, image_size=224, d_txt=768,
-                 syn_steps=8, dtype="bf16", device="cuda", bind=True):
+                 syn_steps=8, dtype="bf16", device="cuda", bind=True, keep_steps=None):
+        """keep_steps: how many inner steps keep their activations in HBM for the outer backward
+        (None = all: nothing is recomputed); the rest are recomputed in one shared slot."""
         self.lib = _lib.load()
         self.variant, self.batch = variant, int(batch)
         self.num_queries = int(num_queries if num_queries is not None else batch)
         self.image_size, self.d_txt, self.syn_steps = int(image_size), int(d_txt), int(syn_steps)
         self.dtype = dtype
         self._variant_b = variant.encode()
+        self.keep_steps = self.syn_steps if keep_steps is None else max(0, min(int(keep_steps), self.syn_steps))
         cfg = MddConfig(self._variant_b, self.batch, self.num_queries, self.image_size, self.d_txt,
-                        self.syn_steps, _DT[dtype])
+                        self.syn_steps, _DT[dtype], -1 if keep_steps is None else int(keep_steps))
+        self.num_slots = self.syn_steps if self.keep_steps >= self.syn_steps else self.keep_steps + 1
         h = C.c_void_p()
         check(self.lib.mdd_engine_create(C.byref(cfg), C.byref(h)))
         self.h = h

@@ -103,3 +103,28 @@ def test_param_tables_of_every_variant_match_the_oracle_flatten_order():
     e0 = UnrollEngine("nfnet_l0", batch=4, bind=False)
     assert e0.P_img == 32769488 and e0.P_img + 2304 * 1000 + 1000 == 35074488 and e0.P_txt == 7087104
     e0.close()
+
+
+def test_c4_workspace_fits_hbm_with_the_recompute_policy():
+    """BASELINE config 4 (COCO, 500 pairs, syn_steps=16, NFNet-l1, bf16; mode A = every GPU runs the
+    whole unroll on its own expert): keeping all 16 steps' activations needs > 1 TB per GPU; with the
+    step-level stash policy (keep_steps=0 -> one shared slot, every step but the last
+    recomputed in the reverse sweep) the plan fits one MI355X's 288 GB, with keep_steps=1 as well."""
+    from multimodal_dataset_distillation_amd.engine import UnrollEngine
+    sizes = {}
+    for keep in (None, 0, 1):
+        eng = UnrollEngine("nfnet_l1", batch=500, num_queries=500, image_size=224, d_txt=768, syn_steps=16,
+                           dtype="bf16", bind=False, keep_steps=keep)
+        sizes[keep] = eng.workspace_bytes
+        assert eng.num_slots == (16 if keep is None else keep + 1)
+        eng.close()
+    print("C4 workspace GiB:", {k: round(v / 2**30, 1) for k, v in sizes.items()})
+    assert sizes[None] > 1000e9                      # not runnable without the policy
+    expert_pair = 2 * 4 * (60_228_712 + 9_449_472)   # theta0 + theta* of one expert (l1 image encoder + 768->3072 head), fp32
+    for keep in (0, 1):
+        assert sizes[keep] + 2 * 500 * (3 * 224 * 224 + 768) * 4 + expert_pair < 288e9
+    # same policy on the benched config: 8 kept steps -> 1 shared slot
+    e = UnrollEngine("nfnet_l0", batch=100, image_size=224, d_txt=768, syn_steps=8, dtype="bf16", bind=False,
+                     keep_steps=0)
+    assert e.workspace_bytes < 0.3 * 79.9 * 2**30 * 1.0 + 2**30
+    e.close()

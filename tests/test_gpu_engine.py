@@ -309,3 +309,49 @@ def test_unrolled_match_minibatch_subset_dropout_and_fixed_scale(report):
                + " ".join(f"{k} {float(v):.2e}" for k, v in e.items()))
         assert all(float(v) < 1e-3 for v in e.values()), e
         eng.close()
+
+
+def test_stash_policy_recompute_matches_keep_all_and_the_oracle(report):
+    """SURVEY 7.5 / VERDICT r1 item 7: with keep_steps < syn_steps the reverse sweep recomputes the
+    forward pass + inner gradient of the steps whose activations were not kept.  nfnet_tiny, K=4,
+    minibatch subsets + dropout masks, f32 mode: every policy must give the oracle's result (1e-3)
+    and agree with keep-all to summation-order noise."""
+    from multimodal_dataset_distillation_amd.engine import UnrollEngine
+    from oracle import distill_ref as dr
+    nq, batch, size, d_txt, K = 6, 4, 64, 32, 4
+    fi, ft = make_oracle("nfnet_tiny", d_txt, 33)
+    feat = ft.module.fc.out_features
+    img, txt = dr.synthetic_inputs(nq, size, d_txt, seed=12)
+    g = torch.Generator().manual_seed(8)
+    perms = [torch.randperm(nq, generator=g)[:batch] for _ in range(K)]
+    masks = [(torch.rand(batch, feat, generator=g) >= 0.1).float() / 0.9 for _ in range(K)]
+    th0i, th0t = fi.flat_param(), ft.flat_param()
+    tgi = th0i + 2e-3 * torch.randn(th0i.shape, generator=g)
+    tgt = th0t + 2e-3 * torch.randn(th0t.shape, generator=g)
+    im, tx = img.clone().requires_grad_(True), txt.clone().requires_grad_(True)
+    lri = torch.tensor(0.1, requires_grad=True); lrt = torch.tensor(0.05, requires_grad=True)
+    grand, info = dr.unrolled_match(fi, ft, im, tx, lri, lrt, th0i, th0t, tgi, tgt, perms, drop_masks=masks)
+    gi, gt_, gli, glt = dr.outer_grads(grand, im, tx, lri, lrt)
+    dev = "cuda"
+    outs = {}
+    for keep in (None, 0, 2, 3):
+        eng = UnrollEngine("nfnet_tiny", batch=batch, num_queries=nq, image_size=size, d_txt=d_txt,
+                           syn_steps=K, dtype="f32", keep_steps=keep)
+        lr = torch.tensor([0.1, 0.05], device=dev)
+        out = eng.unrolled_match(img.to(dev), txt.to(dev), lr[0:1], lr[1:2], th0i.to(dev), th0t.to(dev),
+                                 tgi.to(dev), tgt.to(dev), perms=torch.stack(perms).to(dev),
+                                 drop_masks=torch.stack(masks).to(dev))
+        torch.cuda.synchronize()
+        e = dict(grand=abs(out["grand_loss"].item() - grand.item()) / abs(grand.item()),
+                 ces=rel_err(out["contrastive"], torch.stack(info["contrastive"])),
+                 g_img=rel_err(out["image_syn"], gi), g_txt=rel_err(out["text_syn"], gt_),
+                 g_lri=abs(out["lr"][0].item() - gli.item()) / abs(gli.item()),
+                 g_lrt=abs(out["lr"][1].item() - glt.item()) / abs(glt.item()))
+        report(f"stash policy keep_steps={keep} (slots {eng.num_slots}, ws {eng.workspace_bytes / 2**20:.0f} MiB): "
+               + " ".join(f"{k} {float(v):.2e}" for k, v in e.items()))
+        assert all(float(v) < 1e-3 for v in e.values()), (keep, e)
+        outs[keep] = {k: out[k].detach().clone() for k in ("image_syn", "text_syn", "lr")}
+        eng.close()
+    for keep in (0, 2, 3):
+        d = max(rel_err(outs[keep][k], outs[None][k]) for k in outs[None])
+        assert d < 1e-5, (keep, d)
