@@ -30,6 +30,7 @@ WORKLOADS = {
     # name: (variant, pairs, syn_steps, image, d_txt)
     "c2": ("nfnet_l0", 100, 8, 224, 768),     # BASELINE.json configs[1] -- the metric's config
     "c1": ("nfnet_l0", 10, 2, 224, 768),      # configs[0] (reference's CPU-runnable case)
+    "c4": ("nfnet_l1", 500, 16, 224, 768),    # configs[3] per GPU (mode A); needs --keep-steps 0|1 to fit 288 GB
     "tiny": ("nfnet_tiny", 4, 2, 64, 32),     # plumbing
 }
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md)
@@ -104,6 +105,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-launches", default=None,
                     help="CSV path: one row per contraction launch of the instrumented iteration")
+    ap.add_argument("--keep-steps", type=int, default=None,
+                    help="activation stash policy (engine keep_steps): default keeps every step")
     ap.add_argument("--no-selfcheck", action="store_true",
                     help="skip the post-timing f32-mode gradient check (tools/profile runs)")
     args = ap.parse_args()
@@ -142,8 +145,10 @@ def main():
 
     variant, n, K, size, d_txt = WORKLOADS[args.workload]
     eng = UnrollEngine(variant, batch=n, num_queries=n, image_size=size, d_txt=d_txt, syn_steps=K,
-                       dtype=args.dtype, device=dev)
+                       dtype=args.dtype, device=dev, keep_steps=args.keep_steps)
     lib = _lib.load()
+    if args.workload == "c4":
+        args.no_selfcheck = True     # an f32-mode engine of this size does not fit one GPU
 
     # ---- synthetic inputs: identical on every rank
     g = torch.Generator().manual_seed(0)
@@ -241,6 +246,7 @@ def main():
                                    % (n, K, variant, size, size) if args.workload == "c2"
                        else args.workload,
                        "global_batch": n, "syn_steps": K,
+                       "keep_steps": eng.keep_steps, "workspace_gib": eng.workspace_bytes / 2**30,
                        "parallelism": "expert-replica x%d (1 all-reduce/step)" % world},
             "grand_loss": losses[0], "grand_loss_per_rank": rank_losses,
             "grad_norms": gnorm,
