@@ -13,9 +13,15 @@
 //         rows 8x..8x+3 and 8x+4..8x+7, which with the XOR swizzle below is bank-conflict-free.
 // Output tile BCO x BKP (64x128 for group width 64, 128x128 otherwise), BKM pixels per barrier,
 // one LDS stage, the next tile's global loads in flight (staging registers) during the MFMA phase.
-// The M range is split across blockIdx.y and combined with fp32 atomics (dW is zeroed by the
-// caller).  An optional second pair (dy2, x2) is accumulated too (tangent pass), and the bias
+// The M range is split across blockIdx.y.  With a slab workspace (the engine's path) every split
+// writes its partial tile with plain 16-byte stores into slab[split][g][co][k'] and k_wgrad_reduce sums
+// the slabs into dW (overwriting: no zero-fill, no atomics -- fp32 atomics execute at the memory side at
+// ~1.3 TB/s chip-wide and the 16x16 accumulator layout gave them 64-byte segments); without a slab
+// (single-op entry point) the partials are combined with fp32 atomics into a dW zeroed by the caller.
+// The MFMA operand roles are (x, dy): D rows = k', columns = co, so a lane's four accumulator registers
+// are four CONSECUTIVE k' of one output channel = one 16-byte store.  An optional second pair (dy2, x2) is accumulated too (tangent pass), and the bias
 // gradient (column sums of dy1) is taken from the staging registers of the k'-tile-0 blocks.
+#include <algorithm>
 #include <cstdint>
 #include <type_traits>
 #include <cstdlib>
@@ -31,12 +37,17 @@
 #ifndef MDD_WG_MIN_WAVES
 #define MDD_WG_MIN_WAVES 1
 #endif
+#ifndef MDD_WG_BKM
+#define MDD_WG_BKM 64      // pixels per K-step of the bf16 instances
+#endif
 
 namespace {
 
 struct WArgs {
   const void* dy1; const void* x1; const void* dy2; const void* x2;
   float* dW; float* dbias;
+  float* slab;              // [splits][groups*nc*ktot] partial sums, or null: atomics into dW
+  int64_t slab_stride;      // floats per split
   ConvGeom g;
   int M, cotiles, kptiles, mchunk, dbg;
 };
@@ -306,9 +317,9 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
             bf16x8 a8l = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(al[i][0], al[i][1], 0, 1, 2, 3, 4, 5, 6, 7));
             bf16x8 b8h = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(bh[j][0], bh[j][1], 0, 1, 2, 3, 4, 5, 6, 7));
             bf16x8 b8l = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(bl[j][0], bl[j][1], 0, 1, 2, 3, 4, 5, 6, 7));
-            accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8h, b8h, accb[i][j], 0, 0, 0);
-            accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8h, b8l, accb[i][j], 0, 0, 0);
-            accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8l, b8h, accb[i][j], 0, 0, 0);
+            accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8h, a8h, accb[i][j], 0, 0, 0);
+            accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8l, a8h, accb[i][j], 0, 0, 0);
+            accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8h, a8l, accb[i][j], 0, 0, 0);
           }
       }
     } else if constexpr (!BF) {
@@ -319,8 +330,8 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
         float a0 = *(const float*)(d + r * DROWB + l31 * 4);
         float a1 = *(const float*)(d + r * DROWB + (32 + l31) * 4);
         float b = *(const float*)(x + r * XROWB + (wk * 32 + l31) * 4);
-        accf[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, accf[0], 0, 0, 0);
-        accf[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, accf[1], 0, 0, 0);
+        accf[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a0, accf[0], 0, 0, 0);
+        accf[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a1, accf[1], 0, 0, 0);
       }
     } else {
       const int gq = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
@@ -354,7 +365,7 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
             s16x8 a8 = __builtin_shufflevector(af[i][0], af[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
             s16x8 b8 = __builtin_shufflevector(bfr[j][0], bfr[j][1], 0, 1, 2, 3, 4, 5, 6, 7);
             accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(bf16x8, a8), __builtin_bit_cast(bf16x8, b8), accb[i][j], 0, 0, 0);
+                __builtin_bit_cast(bf16x8, b8), __builtin_bit_cast(bf16x8, a8), accb[i][j], 0, 0, 0);
           }
       }
     }
@@ -372,34 +383,38 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
   }
 
   if (MDD_DBG_BITS(p) & 2) return;   // dbg bit1: no write-out (timing only)
-  // ---- write-out: fp32 atomics into dW[g][co][k']
-  float* dWg = p.dW + (size_t)grp * G.nc * ktot;
+  // ---- write-out.  Accumulator maps (operands (x, dy): rows = k', columns = co):
+  //   32x32 (f32)  : col = lane&31 -> co ; row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> k'
+  //   16x16 (bf16) : col = lane&15 -> co ; row = 4*(lane>>4) + r -> k'
+  // so registers r = 4t..4t+3 are four consecutive k' of one channel: one float4.
+  const size_t gbase = (size_t)grp * G.nc * ktot;
+  float* dst = p.slab ? p.slab + (size_t)bsplit * p.slab_stride + gbase : p.dW + gbase;
+  const bool plain = p.slab != nullptr;
+  auto put4 = [&](int co, int kcol, float v0, float v1, float v2, float v3) {
+    if (co >= G.nc || kcol >= ktot) return;     // ktot and kcol are multiples of 4
+    float* a = dst + (size_t)co * ktot + kcol;
+    if (plain) {
+      *(float4*)a = make_float4(v0, v1, v2, v3);
+    } else {
+      atomicAdd(a, v0); atomicAdd(a + 1, v1); atomicAdd(a + 2, v2); atomicAdd(a + 3, v3);
+    }
+  };
   if constexpr (!TR) {
     const int l31 = lane & 31, lh = lane >> 5;
-    int kcol = kp0 + wk * 32 + l31;
-    if (kcol < ktot) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int co = co0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (co < G.nc) atomicAdd(dWg + (size_t)co * ktot + kcol, accf[i][r]);
-        }
-    }
+      for (int t = 0; t < 4; ++t)
+        put4(co0 + 32 * i + l31, kp0 + wk * 32 + 8 * t + 4 * lh, accf[i][4 * t], accf[i][4 * t + 1],
+             accf[i][4 * t + 2], accf[i][4 * t + 3]);
   } else {
     const int gq = lane >> 4, li = lane & 15;
 #pragma unroll
-    for (int j = 0; j < NBK; ++j) {
-      int kcol = kp0 + wk * WKW + 16 * j + li;
-      if (kcol >= ktot) continue;
+    for (int j = 0; j < NBK; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int co = co0 + wc * 64 + 16 * i + 4 * gq + r;
-          if (co < G.nc) atomicAdd(dWg + (size_t)co * ktot + kcol, accb[i][j][r]);
-        }
-    }
+        put4(co0 + wc * 64 + 16 * i + li, kp0 + wk * WKW + 16 * j + 4 * gq, accb[i][j][0], accb[i][j][1],
+             accb[i][j][2], accb[i][j][3]);
   }
 
   // ---- bias gradient: reduce the per-thread column sums over the rows that share a column
@@ -418,8 +433,34 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
   }
 }
 
+// dW[i] = sum_s slab[s][i]   (one float4 per thread; the split loop is unrolled 8-deep with independent
+// loads in flight -- a serial load->add chain over ~20 splits is pure latency)
+__global__ __launch_bounds__(256) void k_wgrad_reduce(float* __restrict__ dW, const float* __restrict__ slab,
+                                                        int64_t n4, int64_t stride4, int splits) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4* src = (const float4*)slab + i;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  int k = 0;
+  for (; k + 8 <= splits; k += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(k + u) * stride4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+  }
+  {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (k + u < splits) ? src[(int64_t)(k + u) * stride4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+  }
+  ((float4*)dW)[i] = s;
+}
+
 template <class AT, int BCO, int BKP, int BKM>
-void launch_cfg(WArgs a, hipStream_t st) {
+void launch_cfg(WArgs a, float* slab, int64_t slab_floats, hipStream_t st) {
   const bool pw = a.g.k == 1 && a.g.stride == 1 && a.g.pad == 0;
   const ConvGeom& g = a.g;
   int ktot = g.k * g.k * g.kc;
@@ -431,10 +472,16 @@ void launch_cfg(WArgs a, hipStream_t st) {
   // pass over the output tile (chip-wide ~1.3 TB/s).  T(S) = waves(S) * (steps(S) * 1.4 us + 5 us)
   //                                                    + out_bytes * S / 1.3 TB/s + 0.05 us * S.
   const int nsrc = a.dy2 ? 2 : 1;
-  const double out_mb = (double)g.groups * g.nc * ktot * 4.0 / 1e6;
+  const int64_t out_floats = (int64_t)g.groups * g.nc * ktot;
+  const double out_mb = (double)out_floats * 4.0 / 1e6;
+  const bool two_phase = slab != nullptr && slab_floats >= out_floats;
+  // cost of combining one more split: atomics ~1.3 TB/s of added bytes; slabs: one streamed write + one
+  // streamed read of the partial tile (~5 TB/s each)
+  const double comb_us_per_mb = two_phase ? 0.6 : 1.0 / 1.3;
   const int slots = 256 * 3;   // resident blocks on the chip at ~3 blocks per CU
   const double tstep = (g.k == 1 && g.stride == 1) ? 0.8 : 1.4;   // us per K-step (pointwise / gathered)
   int maxsplits = (a.M + 2 * BKM - 1) / (2 * BKM);
+  if (two_phase && maxsplits > slab_floats / out_floats) maxsplits = (int)(slab_floats / out_floats);
   if (maxsplits < 1) maxsplits = 1;
   int splits = 1;
   double best = 1e30;
@@ -443,7 +490,7 @@ void launch_cfg(WArgs a, hipStream_t st) {
     double steps = (double)nsrc * chunk / BKM;
     double waves = (double)((int64_t)tiles * sp + slots - 1) / slots;
     if (waves < 1.0) waves = 1.0;
-    double t = waves * (steps * tstep + 5.0) + out_mb * sp / 1.3 + 0.05 * sp;   // + contention per split
+    double t = waves * (steps * tstep + 5.0) + out_mb * sp * comb_us_per_mb + 0.05 * sp;   // + contention per split
     if (t < best) { best = t; splits = sp; }
   }
   int mchunk = (a.M + splits - 1) / splits;
@@ -456,37 +503,46 @@ void launch_cfg(WArgs a, hipStream_t st) {
 #else
   a.dbg = 0;
 #endif
+  a.slab = two_phase ? slab : nullptr;
+  a.slab_stride = out_floats;
   dim3 grid(tiles, splits);
+  auto finish = [&]() {
+    if (!two_phase) return;
+    int64_t n4 = out_floats / 4;
+    k_wgrad_reduce<<<(unsigned)((n4 + 255) / 256), 256, 0, st>>>(a.dW, slab, n4, out_floats / 4, splits);
+  };
   constexpr bool PF2 = MDD_WG_PF2 && sizeof(AT) == 2 && BCO == 128;   // 2 waves/SIMD either way there
   if constexpr (sizeof(AT) == 4) {
     if (g.prec != 0) {
       if (pw) k_conv_wgrad<AT, BCO, BKP, BKM, true, false, true><<<grid, 256, 0, st>>>(a);
       else k_conv_wgrad<AT, BCO, BKP, BKM, false, false, true><<<grid, 256, 0, st>>>(a);
+      finish();
       return;
     }
   }
   if (pw) k_conv_wgrad<AT, BCO, BKP, BKM, true, PF2, false><<<grid, 256, 0, st>>>(a);
   else k_conv_wgrad<AT, BCO, BKP, BKM, false, false, false><<<grid, 256, 0, st>>>(a);
+  finish();
 }
 
 }  // namespace
 
 template <class AT>
 void launch_conv_wgrad(const ConvGeom& g, const AT* dy1, const AT* x1, const AT* dy2, const AT* x2,
-                       float* dW, float* dbias, hipStream_t st) {
+                       float* dW, float* dbias, float* slab, int64_t slab_floats, hipStream_t st) {
   WArgs a;
   a.dy1 = dy1; a.x1 = x1; a.dy2 = dy2; a.x2 = x2; a.dW = dW; a.dbias = dbias;
   a.g = g;
   a.M = g.nimg * g.ho * g.wo;
   a.cotiles = a.kptiles = a.mchunk = 0;
   if constexpr (sizeof(AT) == 2) {
-    if (g.nc > 64) launch_cfg<AT, 128, 128, 64>(a, st);
-    else launch_cfg<AT, 64, 128, 64>(a, st);
+    if (g.nc > 64) launch_cfg<AT, 128, 128, MDD_WG_BKM>(a, slab, slab_floats, st);
+    else launch_cfg<AT, 64, 128, MDD_WG_BKM>(a, slab, slab_floats, st);
   } else {
-    launch_cfg<AT, 64, 128, 32>(a, st);
+    launch_cfg<AT, 64, 128, 32>(a, slab, slab_floats, st);
   }
 }
 template void launch_conv_wgrad<float>(const ConvGeom&, const float*, const float*, const float*,
-                                       const float*, float*, float*, hipStream_t);
+                                       const float*, float*, float*, float*, int64_t, hipStream_t);
 template void launch_conv_wgrad<bf16>(const ConvGeom&, const bf16*, const bf16*, const bf16*,
-                                      const bf16*, float*, float*, hipStream_t);
+                                      const bf16*, float*, float*, float*, int64_t, hipStream_t);

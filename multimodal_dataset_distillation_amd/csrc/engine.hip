@@ -193,6 +193,8 @@ struct Eng : mdd_engine {
   AT *wf = nullptr, *wt = nullptr, *wf_t = nullptr, *wt_t = nullptr;
   AT *dsS = nullptr, *dsF = nullptr;       // downsample dgrad scratch (pooled / full res)
   float* ln_stats = nullptr;
+  float* wslab[2] = {nullptr, nullptr};             // split-M partial-sum slabs of conv_wgrad: main / side stream
+  int64_t wslab_floats = 0;
   char* lin_mem[3] = {nullptr, nullptr, nullptr};   // split-K scratch: main / side / text stream
   LinScratch lin_main, lin_side, lin_txt;
   float* lossw = nullptr;
@@ -382,6 +384,13 @@ struct Eng : mdd_engine {
     }
     plan(&dsS, dsmax, "dsS", -2); plan(&dsF, dfmax, "dsF", -2);
     for (int i = 0; i < 3; ++i) plan(&lin_mem[i], lin_scratch_bytes(), nullptr, -2);
+    // conv_wgrad split-M slabs: room for ~16 partial copies of the largest dW, at least 64 MiB, per stream
+    {
+      int64_t big = 0;
+      for (auto& L : convs) big = std::max(big, L.packed());
+      wslab_floats = std::max<int64_t>(16 * big, (int64_t)16 << 20);
+      plan(&wslab[0], wslab_floats, nullptr, -2); plan(&wslab[1], wslab_floats, nullptr, -2);
+    }
     plan(&ln_stats, (int64_t)N * 4, nullptr, -2);
     plan(&lossw, loss_work_floats(N, feat), nullptr, -2);
     sets.resize(nslots);
@@ -557,7 +566,8 @@ struct Eng : mdd_engine {
   }
   void wgrad(const ConvL& L, const ConvGeom& g, const AT* dy1, const AT* x1, const AT* dy2, const AT* x2,
              float* dW, float* db, hipStream_t st) {
-    if (!prof_on) { launch_conv_wgrad<AT>(g, dy1, x1, dy2, x2, dW, db, st); return; }
+    float* slab = (use_side && st == side) ? wslab[1] : wslab[0];
+    if (!prof_on) { launch_conv_wgrad<AT>(g, dy1, x1, dy2, x2, dW, db, slab, wslab_floats, st); return; }
     Prof p; int ns = dy2 ? 2 : 1;
     p.kind = 3;
     p.flops = 2.0 * conv_macs(L) * ns;
@@ -565,7 +575,7 @@ struct Eng : mdd_engine {
     p.bytes = (ain + aout) * ns * sizeof(AT) + (double)L.packed() * 4;
     ck(hipEventCreate(&p.a), "hipEventCreate"); ck(hipEventCreate(&p.b), "hipEventCreate");
     ck(hipEventRecord(p.a, st), "hipEventRecord");
-    launch_conv_wgrad<AT>(g, dy1, x1, dy2, x2, dW, db, st);
+    launch_conv_wgrad<AT>(g, dy1, x1, dy2, x2, dW, db, slab, wslab_floats, st);
     ck(hipEventRecord(p.b, st), "hipEventRecord");
     p.g = g; p.ns = ns; prof.push_back(p);
   }
@@ -710,7 +720,7 @@ struct Eng : mdd_engine {
       launch_ws_forward<AT>(d_descs, (int)descs.size(), total_rows, total_tiles, th, T ? th_t : nullptr, wf, wt,
                             wf_t, wt_t, st);
     float* dw = O.dwf; float* dw_t = Q.dwf;
-    HIP_CHECK_RET(hipMemsetAsync(T ? dw_t : dw, 0, packed_total * 4, st));
+    // (no zero-fill of dwf: every conv's two-phase weight gradient overwrites its whole packed slice)
     HIP_CHECK_RET(hipMemsetAsync(gout, 0, P_img * 4, st));
     if (!T && ybar_in != O.yB)
       HIP_CHECK_RET(hipMemcpyAsync(O.yB, ybar_in, (size_t)N * feat * 4, hipMemcpyDeviceToDevice, st));
@@ -1195,9 +1205,9 @@ int mdd_op_conv2d_wgrad(int dtype, int nimg, int hin, int win, int cin, int cout
   if (dtype == MDD_DTYPE_BF16X2) g.prec = 1;
   if (dtype == MDD_DTYPE_F32_BF16OPS) g.prec = 2;
   if (dtype != MDD_DTYPE_BF16)
-    launch_conv_wgrad<float>(g, (const float*)dy, (const float*)x, nullptr, nullptr, dw, db, (hipStream_t)stream);
+    launch_conv_wgrad<float>(g, (const float*)dy, (const float*)x, nullptr, nullptr, dw, db, nullptr, 0, (hipStream_t)stream);
   else
-    launch_conv_wgrad<bf16>(g, (const bf16*)dy, (const bf16*)x, nullptr, nullptr, dw, db, (hipStream_t)stream);
+    launch_conv_wgrad<bf16>(g, (const bf16*)dy, (const bf16*)x, nullptr, nullptr, dw, db, nullptr, 0, (hipStream_t)stream);
   POST_LAUNCH("op_conv2d_wgrad");
   return 0;
 }

@@ -12,7 +12,9 @@ Each network is ONE op with three levels:
 The remaining second-order term (through y -> loss head -> ybar) is an ordinary B with a different
 ybar: autograd calls F.backward again, which runs B with stash=False.
 Cotangents arriving for gx (second order in x alone) are not produced by the reference's loop
-(`autograd.grad` there is w.r.t. theta only) and are rejected loudly.
+(`autograd.grad` there is w.r.t. theta only) and are rejected loudly.  The B ops turn gradient
+materialisation off (`ctx.set_materialize_grads(False)`), so "no cotangent" arrives as None and the
+rejection needs no look at device values: there is NO host synchronisation in any backward.
 """
 import torch
 
@@ -49,14 +51,17 @@ class _ImgB(torch.autograd.Function):
         g = eng.img_backward(slot, _chk(theta.detach()), _chk(ybar.detach()), dimage=gx, stash=stash)
         ctx.eng, ctx.slot = eng, slot
         ctx.save_for_backward(theta, x)
+        ctx.set_materialize_grads(False)
         return g, gx
 
     @staticmethod
     def backward(ctx, u, ux):
         theta, x = ctx.saved_tensors
         eng, slot = ctx.eng, ctx.slot
-        if ux is not None and bool((ux != 0).any()):
+        if ux is not None:
             raise RuntimeError("second-order terms in the image alone are not part of this path")
+        if u is None:
+            return None, None, None, None, None, None
         th = _chk(theta.detach())
         u = _chk(u)
         ydot = eng.img_tangent_forward(slot, th, u)
@@ -91,14 +96,17 @@ class _TxtB(torch.autograd.Function):
         g = eng.txt_backward(slot, _chk(theta.detach()), _chk(ybar.detach()), dtext=gx, stash=stash)
         ctx.eng, ctx.slot = eng, slot
         ctx.save_for_backward(theta, x)
+        ctx.set_materialize_grads(False)
         return g, gx
 
     @staticmethod
     def backward(ctx, u, ux):
         theta, x = ctx.saved_tensors
         eng, slot = ctx.eng, ctx.slot
-        if ux is not None and bool((ux != 0).any()):
+        if ux is not None:
             raise RuntimeError("second-order terms in the text embedding alone are not part of this path")
+        if u is None:
+            return None, None, None, None, None, None
         th = _chk(theta.detach())
         u = _chk(u)
         ydot = eng.txt_tangent_forward(slot, th, u)
@@ -141,6 +149,7 @@ class _ContrastiveB(torch.autograd.Function):
         _, xb, yb, sb = eng.contrastive(_chk(x.detach()), _chk(y.detach()), _chk(s.detach()).view(1))
         ctx.eng = eng
         ctx.save_for_backward(x, y, s)
+        ctx.set_materialize_grads(False)
         return xb, yb, sb.view(s.shape)
 
     @staticmethod
@@ -149,8 +158,10 @@ class _ContrastiveB(torch.autograd.Function):
         # H [ux, uy, us]; the engine's tangent gives the (x, y) columns, the s column is closed-form
         x, y, s = ctx.saved_tensors
         eng = ctx.eng
-        if us is not None and bool((us != 0).any()):
+        if us is not None:
             raise RuntimeError("second order in the logit scale alone is not part of this path")
+        if ux is None and uy is None:
+            return None, None, None, None
         xd = _chk(ux if ux is not None else torch.zeros_like(x))
         yd = _chk(uy if uy is not None else torch.zeros_like(y))
         xbd, ybd, sbd = eng.contrastive_tangent(_chk(x.detach()), _chk(y.detach()), xd, yd,

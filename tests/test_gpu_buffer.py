@@ -80,3 +80,52 @@ def test_buffer_cli_writes_reference_format_and_distill_reads_it(report, tmp_pat
     assert torch.isfinite(img).all() and torch.isfinite(txt).all() and torch.isfinite(lr).all()
     report(f"buffer.py -> {len(files)} files -> distill.py: |image_syn| {img.norm().item():.3f} lr {lr.tolist()}")
     nw.release_engines()
+
+
+def test_stage1_sgd_momentum_weight_decay_and_decay_schedule(report):
+    """reference buffer.py:59-60: torch.optim.SGD(lr, momentum=--mom, weight_decay=--l2) per network, and
+    :97-101 (--decay): lr x0.1 with rebuilt optimisers.  Three steps on fixed flat vectors through
+    optim.sgd_step against torch.optim.SGD itself (CPU), the second pair of steps after a 'decay'."""
+    from multimodal_dataset_distillation_amd.optim import sgd_step
+    torch.manual_seed(0)
+    n, lr, mom, wd = 100003, 0.1, 0.9, 5e-4
+    th = torch.randn(n)
+    grads = [torch.randn(n) for _ in range(4)]
+    p = th.clone().requires_grad_(True)
+    opt = torch.optim.SGD([p], lr=lr, momentum=mom, weight_decay=wd)
+    dev = "cuda"
+    t, buf, first, cur_lr = th.to(dev), torch.zeros(n, device=dev), True, lr
+    for i, g in enumerate(grads):
+        if i == 2:   # --decay: the reference rebuilds the optimiser with lr*0.1 (fresh momentum buffer)
+            opt = torch.optim.SGD([p], lr=lr * 0.1, momentum=mom, weight_decay=wd)
+            cur_lr, first = lr * 0.1, True
+        p.grad = g.clone()
+        opt.step()
+        sgd_step(t, g.to(dev), buf, cur_lr, mom, wd, first)
+        first = False
+        e = rel_err(t.cpu(), p.detach())
+        assert e < 1e-6, (i, e)
+    # momentum 0 / wd 0 (the reference defaults) == plain theta -= lr * g
+    t2, b2 = th.to(dev), torch.zeros(n, device=dev)
+    sgd_step(t2, grads[0].to(dev), b2, lr, 0.0, 0.0, True)
+    assert rel_err(t2.cpu(), th - lr * grads[0]) < 1e-6
+    report("stage-1 SGD(momentum, weight_decay) + decay rebuild == torch.optim.SGD")
+
+
+def test_buffer_cli_honours_mom_l2_decay(report, tmp_path):
+    from multimodal_dataset_distillation_amd import buffer
+    outs = {}
+    for tag, extra in (("plain", []), ("mom", ["--mom", "0.9", "--l2", "0.01", "--decay"])):
+        bdir = str(tmp_path / tag)
+        args = buffer.build_parser().parse_args(
+            ["--dataset", "flickr", "--num_experts", "1", "--train_epochs", "4", "--batch_train", "4",
+             "--image_size", "64", "--image_encoder", "nfnet_tiny", "--synthetic_data", "1",
+             "--compute_dtype", "f32", "--buffer_path", bdir, "--seed", "3"] + extra)
+        buffer.main(args)
+        d = os.path.join(bdir, "flickr", "nfnet_tiny", "bert")
+        traj = torch.load(os.path.join(d, "txt_replay_buffer_0.pt"), map_location="cpu", weights_only=True)
+        outs[tag] = torch.cat([t.reshape(-1) for t in traj[0][-1]])
+        assert torch.isfinite(outs[tag]).all()
+    diff = rel_err(outs["mom"], outs["plain"])
+    report(f"buffer.py --mom 0.9 --l2 0.01 --decay vs defaults: final expert differs by {diff:.2e}")
+    assert diff > 1e-4        # the flags change the trajectory (round 1 dropped them silently)
