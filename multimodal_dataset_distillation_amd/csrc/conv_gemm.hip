@@ -113,6 +113,8 @@ DEVI uint4 mask4(uint4 v, bool keep) {
 }
 DEVI int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+constexpr size_t MODE4_MAX_LDS = 80 * 1024;   // slab mode only when two blocks still share a CU
+
 struct KArgs {
   const void* A1; const void* B1; const void* A2; const void* B2;
   ConvGeom g;
@@ -165,7 +167,8 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
 
   const int ktot_w = G.k * G.k * G.kc;          // K length of one packed weight row
   const int ktot = e_kh * e_kw * G.kc;          // K extent this block reduces over
-  const int nk1 = (ktot + KE - 1) / KE;
+  constexpr int TS = MODE == 4 ? 3 : 1;          // taps per K-step (MODE 4 stages one ROW of taps of B at a time)
+  const int nk1 = (ktot + KE - 1) / KE / TS;
   const int nk = (MDD_DBG_BITS(p) & 1) ? 1 : (p.A2 ? 2 * nk1 : nk1);   // dbg bit0: single K-step (timing only)
 
   // ---- per-thread staging geometry, hoisted out of the K loop (the loop is instruction-issue
@@ -196,6 +199,8 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
       int mm = m < e_M ? m : e_M - 1;          // clamp: rows >= M are computed but never stored
       aoff[i] = (mm * G.ca_tot + cj * CE) * ESZ;
       tapm[i] = 1u;
+    } else if constexpr (MODE == 4) {
+      aoff[i] = 0; tapm[i] = 0u;               // MODE 4 stages no A rows through registers (slab below)
     } else {
       aoff[i] = 0; tapm[i] = 0u;
       if constexpr (MODE == 3) { s2y[i] = -1; s2x[i] = -1; s2b[i] = 0; }
@@ -237,7 +242,17 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
   // LDS byte addresses.  Rows 32 apart share the swizzle, so the i / j sub-tiles are reached with
   // immediate offsets (i * 4096) from ONE register per q.  (With MDD_SINGLE_BUF=0 a second LDS stage is
   // toggled by XOR-ing one bit into these few registers per K-step: buffer strides are powers of two.)
-  constexpr int ABUF = NBUF == 2 ? BM * 128 : 0, BBUF = NBUF == 2 ? BN * 128 : 0, BBASE = NBUF * BM * 128;
+  constexpr int ABUF = NBUF == 2 ? BM * 128 : 0, BBUF = NBUF == 2 ? BN * 128 : 0;
+  // MODE 4 (3x3, stride 1, "same" size, one 128-byte channel row per pixel and group): the A operand of
+  // ALL nine taps is one contiguous slab of the NHWC tensor -- source pixel = m + (ty-1)*W + (tx-1) for every
+  // tap that lies inside the image -- so the block loads pixels [m0-W-1, m0+BM+W] ONCE into LDS and the
+  // K loop (one ROW of three taps per step: 24 KB of B per stage, so the next stage's weight loads have three
+  // taps of MFMAs to hide behind) reads its A fragments from the slab at a per-tap pixel offset; taps outside
+  // the image (per-row bit mask, as in MODE 1) read a row of zeros.  MODE 1 fetched the same pixels nine
+  // times through L1 with one latency-bound round trip per tap.
+  const int slab_pad = e_wo + 1;
+  const int slab_pix = BM + 2 * e_wo + 2;
+  const int BBASE = MODE == 4 ? (slab_pix + 1) * 128 : NBUF * BM * 128;
   const int l31 = lane & 31, lh = lane >> 5;
   int rdA[4], rdB[4];
 #pragma unroll
@@ -246,6 +261,28 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
     rdB[q] = BBASE + lds_off(wn * TN * 32 + l31, 2 * q + lh);
   }
   int wrA = lds_off(r0, cj), wrB = BBASE + lds_off(r0, cj);   // stage 0 goes to buffer 0
+  // MODE 4: slab pixel of this lane's fragment rows at the centre tap, and their tap-validity masks
+  int sp0[MODE == 4 ? TM : 1];
+  unsigned tapf[MODE == 4 ? TM : 1];
+  if constexpr (MODE == 4) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = wm * TM * 32 + i * 32 + l31, m = m0 + row;
+      sp0[i] = row + slab_pad;
+      tapf[i] = 0u;
+      if (m < e_M) {
+        const int ox = m % e_wo, oy = (m / e_wo) % e_ho;
+        int ylo, yhi, xlo, xhi;
+        if (G.transposed) { const int y0 = oy + G.pad, x0 = ox + G.pad; ylo = y0 - (G.ha - 1); yhi = y0; xlo = x0 - (G.wa - 1); xhi = x0; }
+        else { const int y0 = oy - G.pad, x0 = ox - G.pad; ylo = -y0; yhi = G.ha - 1 - y0; xlo = -x0; xhi = G.wa - 1 - x0; }
+        ylo = max(ylo, 0); xlo = max(xlo, 0); yhi = min(yhi, 2); xhi = min(xhi, 2);
+        const unsigned xm = (xhi >= xlo) ? (((1u << (xhi - xlo + 1)) - 1u) << xlo) : 0u;
+        unsigned tm_ = 0u;
+        for (int ty = ylo; ty <= yhi; ++ty) tm_ |= xm << (ty * 3);
+        tapf[i] = tm_;
+      }
+    }
+  }
 
   // K cursor of this thread's chunk column (generic path): advanced with compare/subtract only
   int c_kidx = cj * CE, c_tap = 0, c_kcq = 0, c_ty = 0, c_tx = 0, c_tapoff = 0;
@@ -260,14 +297,16 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
   };
   if constexpr (MODE != 0) cursor_init();
 
-  struct Stage { u32x4 ra[RA], rb[RB]; };
+  struct Stage { u32x4 ra[RA], rb[RB * TS]; };
   Stage s0;
   auto load_tile = [&](int kt, Stage& S) __attribute__((always_inline)) {
     const bool second = kt >= nk1;
     const char* A = (const char*)(second ? p.A2 : p.A1);
     const char* B = (const char*)(second ? p.B2 : p.B1);
     const int ks = second ? kt - nk1 : kt;          // K-step within the source
-    if constexpr (MODE == 0) {
+    if constexpr (MODE == 4) {
+      (void)A;                                      // the A operand lives in the LDS slab
+    } else if constexpr (MODE == 0) {
       const char* Ak = A + ks * 128;                // uniform base: zero VALU per load
       const bool kok = KFULL || (ks * KE + cj * CE) < ktot;
 #pragma unroll
@@ -307,7 +346,13 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
           S.rb[i] = *(const u32x4*)(bok2 ? B + (boff[i] + bt) : Z);
       }
     }
-    if constexpr (MODE != 2) {
+    if constexpr (MODE == 4) {
+      const char* Bk = B + ks * (TS * 128);         // three taps = three consecutive 128-byte K rows
+#pragma unroll
+      for (int t = 0; t < TS; ++t)
+#pragma unroll
+        for (int i = 0; i < RB; ++i) S.rb[t * RB + i] = *(const u32x4*)(Bk + (unsigned)boff[i] + t * 128);
+    } else if constexpr (MODE != 2) {
       const char* Bk = B + ks * 128;
       const bool kok = KFULL || (ks * KE + cj * CE) < ktot;
 #pragma unroll
@@ -326,13 +371,65 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
 
   const bool hi_only = PREC == 1 && p.g.prec == 2;   // attribution experiment: fp32 stash, bf16 operands
   auto store_tile = [&](const Stage& S) __attribute__((always_inline)) {
+    if constexpr (MODE != 4) {
 #pragma unroll
-    for (int i = 0; i < RA; ++i) *(u32x4*)(smem + wrA + i * 4096) = MT::stage(S.ra[i], hi_only);
+      for (int i = 0; i < RA; ++i) *(u32x4*)(smem + wrA + i * 4096) = MT::stage(S.ra[i], hi_only);
+    }
 #pragma unroll
-    for (int i = 0; i < RB; ++i) *(u32x4*)(smem + wrB + i * 4096) = MT::stage(S.rb[i], hi_only);
+    for (int t = 0; t < TS; ++t)
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+        *(u32x4*)(smem + wrB + t * (BN * 128) + i * 4096) = MT::stage(S.rb[t * RB + i], hi_only);
     wrA ^= ABUF; wrB ^= BBUF;
   };
-  auto compute = [&]() __attribute__((always_inline)) {
+  // MODE 4: pixels [m0 - W - 1, m0 + BM + W] of this group's channel row -> LDS, eight 16-byte loads per
+  // thread in flight at a time; pixels before / after the tensor read zeros (only masked taps touch them)
+  auto load_slab = [&](const void* Asrc) __attribute__((always_inline)) {
+    const int p_lo = m0 - slab_pad;
+    const int nch = slab_pix * 8;
+    const char* Ag = (const char*)Asrc + (size_t)grp * G.kc * ESZ + cj * 16;
+    for (int base = 0; base < nch; base += 2048) {
+      u32x4 r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int pl = (base >> 3) + 32 * u + r0, pg = p_lo + pl;
+        const bool ok = pl < slab_pix && pg >= 0 && pg < p.M;
+        r[u] = *(const u32x4*)(ok ? Ag + (size_t)pg * G.ca_tot * ESZ : Z);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int pl = (base >> 3) + 32 * u + r0;
+        if (pl < slab_pix) *(u32x4*)(smem + lds_off(pl, cj)) = r[u];
+      }
+    }
+  };
+  auto compute = [&](int kt) __attribute__((always_inline)) {
+    if constexpr (MODE == 4) {
+      const int ty = kt >= nk1 ? kt - nk1 : kt;       // this step = the three taps (ty, 0..2)
+#pragma unroll
+      for (int tx = 0; tx < TS; ++tx) {
+        const int tap = ty * 3 + tx;
+        const int toff = G.transposed ? (1 - ty) * e_wo + (1 - tx) : (ty - 1) * e_wo + (tx - 1);
+        int abase[TM], asw[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int sp = ((tapf[i] >> tap) & 1u) ? sp0[i] + toff : slab_pix;   // slab_pix = the row of zeros
+          abase[i] = sp * 128; asw[i] = (sp >> 1) & 7;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          u32x4 af[TM], bf[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[i] = *(const u32x4*)(smem + abase[i] + (((2 * q + lh) ^ asw[i]) << 4));
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bf[j] = *(const u32x4*)(smem + rdB[q] + tx * (BN * 128) + j * 4096);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) MT::step(af[i], bf[j], acc[i][j]);
+        }
+      }
+    } else
     if constexpr (MDD_FRAG_PREFETCH && sizeof(AT) == 2 && MODE == 0) {
     // the LDS fragments of K-slice q+1 are fetched before the MFMAs of slice q are issued (the scheduling
     // barriers keep the compiler from sinking the fetch back next to its use): +11..14 % on the long-K,
@@ -374,12 +471,22 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
 #pragma unroll
     for (int q = 0; q < 4; ++q) { rdA[q] ^= ABUF; rdB[q] ^= BBUF; }
   };
+  if constexpr (MODE == 4) {
+    if (tid < 8) *(u32x4*)(smem + slab_pix * 128 + tid * 16) = u32x4{0u, 0u, 0u, 0u};
+    load_slab(p.A1);
+  }
   load_tile(0, s0);
   store_tile(s0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) load_tile(kt + 1, s0);
-    compute();
+    if constexpr (MODE == 4) {
+      if (kt == nk1) {      // second source of a tangent launch: its slab replaces the first one's
+        load_slab(p.A2);    // (every wave is past the barrier that ended the last step on slab 1)
+        __syncthreads();
+      }
+    }
+    compute(kt);
     if (NBUF == 1) __syncthreads();      // everyone is done reading the slab before it is replaced
     if (kt + 1 < nk) store_tile(s0);
     __syncthreads();
@@ -548,6 +655,7 @@ void launch_cfg(const KArgs& a, hipStream_t st) {
   if (MODE == 2) k.mtiles = 4 * ((a.g.nimg * (a.g.ho / 2) * (a.g.wo / 2) + BM - 1) / BM);
   k.ntiles = (a.g.nc + BN - 1) / BN;
   size_t shm = (MDD_SINGLE_BUF ? 1 : 2) * (BM + BN) * 128;
+  if (MODE == 4) shm = (size_t)(BM + 2 * a.g.wo + 3) * 128 + (size_t)3 * BN * 128;   // slab + zero row + B stage (3 taps)
   size_t shm_epi = 4 * (size_t)32 * (TN * 32 + 4) * sizeof(float);  // per-wave transpose, 32 rows at a time
   if (shm_epi > shm) shm = shm_epi;
   // the dynamic-LDS limit is a per-device function attribute: set it once per (instance, device)
@@ -557,7 +665,8 @@ void launch_cfg(const KArgs& a, hipStream_t st) {
   const uint64_t bit = 1ull << (dev & 63);
   if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
     hipError_t e = hipFuncSetAttribute((const void*)k_conv_gemm<AT, WGM, WGN, TM, TN, MODE, KFULL, PREC>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       MODE == 4 ? (int)MODE4_MAX_LDS : (int)shm);
     if (e == hipSuccess) attr_devs.fetch_or(bit, std::memory_order_release);
   }
   int64_t blocks = (int64_t)k.mtiles * k.ntiles * a.g.groups;
@@ -587,6 +696,12 @@ void launch_conv_gemm(const ConvGeom& g, const AT* A1, const AT* B1, const AT* A
   const bool s2t = g.transposed && g.stride == 2;
   const int mode = pw ? 0 : (s2t ? (((g.ho | g.wo) & 1) == 0 && g.k <= 3 ? 2 : 3) : 1);
   const bool kfull = ((g.k * g.k * g.kc) % Mma<AT>::KE) == 0;
+  if constexpr (sizeof(AT) == 2) {
+    // MODE 4: 3x3 stride-1 "same" conv (forward or data gradient) whose group is one 128-byte channel row
+    const bool slab = g.k == 3 && g.stride == 1 && g.pad == 1 && g.kc == 64 && g.nc <= 64 && g.ha == g.ho &&
+                      g.wa == g.wo && (size_t)(256 + 2 * g.wo + 3) * 128 + 3 * 64 * 128 <= MODE4_MAX_LDS;
+    if (slab) { launch_cfg<AT, 4, 1, 2, 2, 4, true, 0>(a, st); return; }
+  }
 #define MDD_DISPATCH_P(WGM, WGN, TM, TN, PREC)                                                \
   do {                                                                                        \
     if (mode == 0) { if (kfull) launch_cfg<AT, WGM, WGN, TM, TN, 0, true, PREC>(a, st);      \

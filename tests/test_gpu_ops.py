@@ -23,6 +23,12 @@ CASES = [
     (3, 7, 96, 160, 1, 1, 1),     # 1x1, ragged M (147 rows), N=160 -> partial N tile
     (2, 9, 32, 48, 3, 2, 1),      # odd spatial size with stride 2
     (5, 1, 64, 40, 1, 1, 1),      # M = 5 (linear-layer-like)
+    # 3x3 stride-1 convs with 64-channel groups: the LDS-slab path (MODE 4) in bf16 -- tiles that straddle
+    # image boundaries at every feature-map width of NFNet-l0 (7, 14, 28, 56), ragged last tile
+    (11, 7, 128, 128, 3, 1, 2),
+    (5, 14, 192, 192, 3, 1, 3),
+    (3, 28, 128, 128, 3, 1, 2),
+    (2, 56, 64, 64, 3, 1, 1),
 ]
 
 

@@ -3,12 +3,15 @@ import ctypes as C, sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from multimodal_dataset_distillation_amd import _lib
+if len(sys.argv) > 1:            # tools/bench_conv.py <library.so>: time another build (A/B)
+    _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 lib = _lib.load()
 dev = "cuda"
 P = lambda t: C.c_void_p(t.data_ptr())
 SHAPES = [  # nimg, h, cin, cout, k, stride, groups
     (100, 14, 384, 1536, 1, 1, 1), (100, 14, 1536, 384, 1, 1, 1), (100, 14, 384, 384, 3, 1, 6),
     (100, 56, 64, 256, 1, 1, 1), (100, 112, 32, 64, 3, 1, 1),
+    (100, 28, 128, 128, 3, 1, 2), (100, 56, 64, 64, 3, 1, 1), (100, 7, 384, 384, 3, 1, 6),
 ]
 for (n, h, cin, cout, k, s, g) in SHAPES:
     pad = ((s - 1) + (k - 1)) // 2
@@ -30,4 +33,4 @@ for (n, h, cin, cout, k, s, g) in SHAPES:
     us = e0.elapsed_time(e1) / R * 1e3
     flops = 2.0 * n * ho * ho * cout * (cin // g) * k * k
     byts = (x.numel() + w.numel() + y.numel()) * 2
-    print("dbg=%s %s: %.1f us  %.0f TF/s  %.0f GB/s" % (os.environ.get("MDD_DBG", "0"), (n, h, cin, cout, k, s, g), us, flops / us / 1e6, byts / us / 1e3))
+    print("lib=%s dbg=%s %s: %.1f us  %.0f TF/s  %.0f GB/s" % (os.path.basename(_lib.LIB_PATH), os.environ.get("MDD_DBG", "0"), (n, h, cin, cout, k, s, g), us, flops / us / 1e6, byts / us / 1e3))
