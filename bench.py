@@ -36,7 +36,7 @@ WORKLOADS = {
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
-KIND_NAMES = ["conv_gemm<128x32>", "conv_gemm<256x64>", "conv_gemm<128x128>", "conv_wgrad"]
+KIND_NAMES = ["conv_gemm<128x32>", "conv_gemm<256x64>", "conv_gemm<128x128>", "conv_wgrad", "k_wgrad_reduce"]
 TRAFFIC_FILES = ["traffic_r02.json", "traffic_r01.json"]      # newest first
 # Budget for the post-timing self-check: relative error of the benched mode's outer gradients against ONE
 # f32-mode (exact-fp32 MFMA) iteration on the same inputs.  ~2x the errors measured on MI355X.
@@ -273,7 +273,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         kinds = []
         buf = (C.c_double * 4)()
-        for k in range(4):
+        for k in range(len(KIND_NAMES)):
             _lib.check(lib.mdd_engine_profile_read(eng.h, k, buf))
             kinds.append(dict(kernel=KIND_NAMES[k], launches=int(buf[0]), ms=buf[1], flops=buf[2],
                               bytes=buf[3]))
@@ -283,7 +283,7 @@ def main():
         lib.mdd_engine_profile(eng.h, 0)
         # dominant kernel class = most time per iteration.  Its roofline is the one its ALGORITHMIC
         # arithmetic intensity selects: below the ridge (peak flops / peak HBM bytes) it is HBM-bound.
-        dom = max(kinds, key=lambda d: d["ms"])
+        dom = max((d for d in kinds if d["flops"] > 0), key=lambda d: d["ms"])
         peak_tf = PEAK_F32_TFLOPS if args.dtype == "f32" else PEAK_BF16_TFLOPS   # bf16x2 issues bf16 MFMAs
         secs = dom["ms"] * 1e-3
         tfs = dom["flops"] / secs / 1e12 if secs > 0 else 0.0

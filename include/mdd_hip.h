@@ -166,7 +166,8 @@ typedef struct mdd_iter_args {
 int mdd_unrolled_match(mdd_engine* e, const mdd_iter_args* a, void* stream);
 
 /* ---- per-kernel HIP-event timing of the contraction launches (bench.py roofline accounting).
- * kind: 0 = conv_gemm 128x32 tile, 1 = conv_gemm 256x64, 2 = conv_gemm 128x128, 3 = conv_wgrad.
+ * kind: 0 = conv_gemm 128x32 tile, 1 = conv_gemm 256x64, 2 = conv_gemm 128x128, 3 = conv_wgrad (the
+ * contraction kernel alone), 4 = the split-M reduce kernel that follows each conv_wgrad.
  * out4 = {launches, total milliseconds, algorithmic FLOPs, algorithmic bytes} since enable. */
 int mdd_engine_profile(mdd_engine* e, int enable);
 int mdd_engine_profile_read(mdd_engine* e, int kind, double* out4);

@@ -433,34 +433,39 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
   }
 }
 
-// dW[i] = sum_s slab[s][i]   (one float4 per thread; the split loop is unrolled 8-deep with independent
-// loads in flight -- a serial load->add chain over ~20 splits is pure latency)
+// dW[i] = sum_s slab[s][i].  A block owns 16 consecutive float4 columns; its 256 threads are 16 split lanes
+// x 16 columns: lane l sums splits l, l+16, ... (8 independent 16-byte loads in flight), the 16 partial sums
+// of a column meet in LDS.  Layers with tiny outputs run thousands of splits (stem: M = 1.25 M pixels onto a
+// 4.6 K-float dW): one thread per column walking all of them serially took >100 us on the pass's tail.
 __global__ __launch_bounds__(256) void k_wgrad_reduce(float* __restrict__ dW, const float* __restrict__ slab,
                                                         int64_t n4, int64_t stride4, int splits) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n4) return;
-  const float4* src = (const float4*)slab + i;
+  __shared__ float4 part[16][17];
+  const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int64_t i = (int64_t)blockIdx.x * 16 + col;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  int k = 0;
-  for (; k + 8 <= splits; k += 8) {
-    float4 v[8];
+  if (i < n4) {
+    const float4* src = (const float4*)slab + i;
+    for (int k = sl; k < splits; k += 16 * 8) {
+      float4 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(k + u) * stride4];
+      for (int u = 0; u < 8; ++u)
+        v[u] = (k + 16 * u < splits) ? src[(int64_t)(k + 16 * u) * stride4] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
   }
-  {
-    float4 v[8];
+  part[sl][col] = s;
+  __syncthreads();
+  if (sl == 0 && i < n4) {
+    float4 t = part[0][col];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = (k + u < splits) ? src[(int64_t)(k + u) * stride4] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    for (int l = 1; l < 16; ++l) { float4 v = part[l][col]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    ((float4*)dW)[i] = t;
   }
-  ((float4*)dW)[i] = s;
 }
 
 template <class AT, int BCO, int BKP, int BKM>
-void launch_cfg(WArgs a, float* slab, int64_t slab_floats, hipStream_t st) {
+void launch_cfg(WArgs a, float* slab, int64_t slab_floats, hipEvent_t ev_mid, hipStream_t st) {
   const bool pw = a.g.k == 1 && a.g.stride == 1 && a.g.pad == 0;
   const ConvGeom& g = a.g;
   int ktot = g.k * g.k * g.kc;
@@ -507,9 +512,10 @@ void launch_cfg(WArgs a, float* slab, int64_t slab_floats, hipStream_t st) {
   a.slab_stride = out_floats;
   dim3 grid(tiles, splits);
   auto finish = [&]() {
+    if (ev_mid) (void)hipEventRecord(ev_mid, st);    // profiling: end of the contraction kernel proper
     if (!two_phase) return;
     int64_t n4 = out_floats / 4;
-    k_wgrad_reduce<<<(unsigned)((n4 + 255) / 256), 256, 0, st>>>(a.dW, slab, n4, out_floats / 4, splits);
+    k_wgrad_reduce<<<(unsigned)((n4 + 15) / 16), 256, 0, st>>>(a.dW, slab, n4, out_floats / 4, splits);
   };
   constexpr bool PF2 = MDD_WG_PF2 && sizeof(AT) == 2 && BCO == 128;   // 2 waves/SIMD either way there
   if constexpr (sizeof(AT) == 4) {
@@ -529,20 +535,21 @@ void launch_cfg(WArgs a, float* slab, int64_t slab_floats, hipStream_t st) {
 
 template <class AT>
 void launch_conv_wgrad(const ConvGeom& g, const AT* dy1, const AT* x1, const AT* dy2, const AT* x2,
-                       float* dW, float* dbias, float* slab, int64_t slab_floats, hipStream_t st) {
+                       float* dW, float* dbias, float* slab, int64_t slab_floats, hipEvent_t ev_mid,
+                       hipStream_t st) {
   WArgs a;
   a.dy1 = dy1; a.x1 = x1; a.dy2 = dy2; a.x2 = x2; a.dW = dW; a.dbias = dbias;
   a.g = g;
   a.M = g.nimg * g.ho * g.wo;
   a.cotiles = a.kptiles = a.mchunk = 0;
   if constexpr (sizeof(AT) == 2) {
-    if (g.nc > 64) launch_cfg<AT, 128, 128, MDD_WG_BKM>(a, slab, slab_floats, st);
-    else launch_cfg<AT, 64, 128, MDD_WG_BKM>(a, slab, slab_floats, st);
+    if (g.nc > 64) launch_cfg<AT, 128, 128, MDD_WG_BKM>(a, slab, slab_floats, ev_mid, st);
+    else launch_cfg<AT, 64, 128, MDD_WG_BKM>(a, slab, slab_floats, ev_mid, st);
   } else {
-    launch_cfg<AT, 64, 128, 32>(a, slab, slab_floats, st);
+    launch_cfg<AT, 64, 128, 32>(a, slab, slab_floats, ev_mid, st);
   }
 }
 template void launch_conv_wgrad<float>(const ConvGeom&, const float*, const float*, const float*,
-                                       const float*, float*, float*, float*, int64_t, hipStream_t);
+                                       const float*, float*, float*, float*, int64_t, hipEvent_t, hipStream_t);
 template void launch_conv_wgrad<bf16>(const ConvGeom&, const bf16*, const bf16*, const bf16*,
-                                      const bf16*, float*, float*, float*, int64_t, hipStream_t);
+                                      const bf16*, float*, float*, float*, int64_t, hipEvent_t, hipStream_t);

@@ -463,7 +463,7 @@ struct Eng : mdd_engine {
     if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
     if (tside) { (void)hipStreamSynchronize(tside); (void)hipStreamDestroy(tside); }
     for (auto e : evs) (void)hipEventDestroy(e);
-    for (auto& p : prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto& p : prof) { if (!p.shared_a) (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   }
   std::vector<hipEvent_t> evs;
   size_t evi = 0;
@@ -513,11 +513,11 @@ struct Eng : mdd_engine {
   void join_from(hipStream_t from, hipStream_t to) { fork_to(to, from); }
 
   // ---- optional HIP-event timing of every contraction launch (bench.py roofline accounting)
-  struct Prof { int kind; double flops, bytes; hipEvent_t a, b; ConvGeom g; int ns; };
+  struct Prof { int kind; double flops, bytes; hipEvent_t a, b; ConvGeom g; int ns; bool shared_a = false; };
   bool prof_on = false;
   std::vector<Prof> prof;
   void profile_enable(bool on) override {
-    for (auto& p : prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto& p : prof) { if (!p.shared_a) (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     prof.clear(); prof_on = on;
   }
   int profile_read(int kind, double* out) override {  // {launches, total ms, flops, bytes}
@@ -567,7 +567,7 @@ struct Eng : mdd_engine {
   void wgrad(const ConvL& L, const ConvGeom& g, const AT* dy1, const AT* x1, const AT* dy2, const AT* x2,
              float* dW, float* db, hipStream_t st) {
     float* slab = (use_side && st == side) ? wslab[1] : wslab[0];
-    if (!prof_on) { launch_conv_wgrad<AT>(g, dy1, x1, dy2, x2, dW, db, slab, wslab_floats, st); return; }
+    if (!prof_on) { launch_conv_wgrad<AT>(g, dy1, x1, dy2, x2, dW, db, slab, wslab_floats, nullptr, st); return; }
     Prof p; int ns = dy2 ? 2 : 1;
     p.kind = 3;
     p.flops = 2.0 * conv_macs(L) * ns;
@@ -575,9 +575,14 @@ struct Eng : mdd_engine {
     p.bytes = (ain + aout) * ns * sizeof(AT) + (double)L.packed() * 4;
     ck(hipEventCreate(&p.a), "hipEventCreate"); ck(hipEventCreate(&p.b), "hipEventCreate");
     ck(hipEventRecord(p.a, st), "hipEventRecord");
-    launch_conv_wgrad<AT>(g, dy1, x1, dy2, x2, dW, db, slab, wslab_floats, st);
-    ck(hipEventRecord(p.b, st), "hipEventRecord");
+    // [a, b] brackets the contraction kernel alone (b is recorded by the launcher before the split-M
+    // reduce kernel), [b, c] the reduce kernel: kind 4
+    Prof r; r.kind = 4; r.flops = 0; r.bytes = 0; r.g = g; r.ns = ns; r.a = p.b;
+    ck(hipEventCreate(&r.b), "hipEventCreate");
+    launch_conv_wgrad<AT>(g, dy1, x1, dy2, x2, dW, db, slab, wslab_floats, p.b, st);
+    ck(hipEventRecord(r.b, st), "hipEventRecord");
     p.g = g; p.ns = ns; prof.push_back(p);
+    r.shared_a = true; prof.push_back(r);
   }
 
   // c = conv(in) + bias ; C <- c ; A <- beta*silu(c).   T: tangent of the same (primal from stash)
@@ -1153,7 +1158,7 @@ int mdd_engine_profile_dump(mdd_engine* e, const char* path) {
   return e->profile_dump(path);
 }
 int mdd_engine_profile_read(mdd_engine* e, int kind, double* out4) {
-  CHECK_ARG(e && out4 && kind >= 0 && kind < 4, "profile_read");
+  CHECK_ARG(e && out4 && kind >= 0 && kind < 5, "profile_read");
   return e->profile_read(kind, out4);
 }
 int mdd_unrolled_match(mdd_engine* e, const mdd_iter_args* a, void* stream) {
@@ -1205,9 +1210,9 @@ int mdd_op_conv2d_wgrad(int dtype, int nimg, int hin, int win, int cin, int cout
   if (dtype == MDD_DTYPE_BF16X2) g.prec = 1;
   if (dtype == MDD_DTYPE_F32_BF16OPS) g.prec = 2;
   if (dtype != MDD_DTYPE_BF16)
-    launch_conv_wgrad<float>(g, (const float*)dy, (const float*)x, nullptr, nullptr, dw, db, nullptr, 0, (hipStream_t)stream);
+    launch_conv_wgrad<float>(g, (const float*)dy, (const float*)x, nullptr, nullptr, dw, db, nullptr, 0, nullptr, (hipStream_t)stream);
   else
-    launch_conv_wgrad<bf16>(g, (const bf16*)dy, (const bf16*)x, nullptr, nullptr, dw, db, nullptr, 0, (hipStream_t)stream);
+    launch_conv_wgrad<bf16>(g, (const bf16*)dy, (const bf16*)x, nullptr, nullptr, dw, db, nullptr, 0, nullptr, (hipStream_t)stream);
   POST_LAUNCH("op_conv2d_wgrad");
   return 0;
 }

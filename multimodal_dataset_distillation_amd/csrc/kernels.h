@@ -91,10 +91,12 @@ void launch_conv_gemm(const ConvGeom& g, const AT* A1, const AT* B1, const AT* A
 //     stores into slab[split][...], then a reduce kernel OVERWRITES dW (no zero-fill needed);
 //   slab == null: fp32 atomics into dW, which the caller must have zeroed.
 // optional second pair (dy2, x2) accumulated as well; optional bias grad db[co] += sum_m dy[m][co]
-// (always atomics into a zeroed db: cout floats).
+// (always atomics into a zeroed db: cout floats).  ev_mid (optional, profiling): recorded between the
+// contraction kernel and the reduce kernel.
 template <class AT>
 void launch_conv_wgrad(const ConvGeom& g, const AT* dy1, const AT* x1, const AT* dy2, const AT* x2,
-                       float* dW, float* dbias, float* slab, int64_t slab_floats, hipStream_t st);
+                       float* dW, float* dbias, float* slab, int64_t slab_floats, hipEvent_t ev_mid,
+                       hipStream_t st);
 
 // ---------------------------------------------------------------- elementwise.hip
 template <class AT>

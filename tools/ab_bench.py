@@ -49,13 +49,13 @@ def one(lib_path, dtype, steps, workload):
     torch.cuda.synchronize()
     buf = (C.c_double * 4)()
     kinds = []
-    for k in range(4):
+    for k in range(5):
         _lib.check(lib.mdd_engine_profile_read(eng.h, k, buf))
         kinds.append(round(buf[1], 2))
     lib.mdd_engine_profile(eng.h, 0)
     print(json.dumps({"lib": os.path.basename(lib_path), "dtype": dtype, "ms_per_iter": round(ms, 2),
                       "grand": float(out["grand_loss"]), "gnorm": float(out["image_syn"].norm()),
-                      "class_ms[128x32,256x64,128x128,wgrad]": kinds}), flush=True)
+                      "class_ms[128x32,256x64,128x128,wgrad,wgrad_reduce]": kinds}), flush=True)
 
 
 def main():
