@@ -11,10 +11,14 @@ step with the reference's optimiser semantics -- torch.optim.SGD(lr, momentum=--
 weight_decay=--l2) per network (buffer.py:59-60), rebuilt with lr*0.1 after epoch
 train_epochs//2+1 under --decay (buffer.py:97-101; the reference multiplies an undefined `lr`
 there -- the intent, both teacher learning rates x0.1 and fresh momentum buffers, is what runs
-here) -- and the reference's fixed logit scale 1/0.07 (networks.py:878).  Real Flickr30K/COCO batches need
-the dataset + frozen BERT embeddings, which do not exist offline, so the only data source wired up is
-`--synthetic_data` (random image / text-embedding pairs): good for exercising the pipeline and for
-producing buffers in the reference format on an MI355X, not for training useful experts.
+here) -- and the reference's fixed logit scale 1/0.07 (networks.py:878).
+Data sources: `--train_images FILE` (tensor file [M,3,S,S] of the training images in annotation order)
++ the train-caption embedding cache `{dataset}_{text_encoder}_train_text_embed.npz` (reference
+utils.py:885; with precomputed embeddings the reference's `epoch` takes `caption` as a tensor,
+networks.py:866-867): real (image, caption) pairs, one shuffled pass per epoch like the reference's
+DataLoader, optional per-epoch retrieval metrics on `--eval_data` (buffer.py:74-75); or
+`--synthetic_data STEPS` (random pairs) to exercise the pipeline without a dataset.  Decoding JPEGs,
+augmentation and running BERT are outside the MI355X path.
 """
 import argparse
 import datetime
@@ -65,6 +69,12 @@ def build_parser():
                    help="train on random pairs, this many steps per epoch (no dataset offline)")
     p.add_argument("--compute_dtype", default="bf16", choices=["bf16", "bf16x2", "f32"])
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--train_images", type=str, default=None,
+                   help="tensor file (.pt/.npy/.npz key 'images') [M,3,S,S]: training images, annotation order")
+    p.add_argument("--embed_dir", type=str, default=".",
+                   help="directory of {dataset}_{text_encoder}_train_text_embed.npz (reference utils.py:885)")
+    p.add_argument("--eval_data", type=str, default=None,
+                   help=".npz held-out retrieval set (images, txt2img[, bert_test_embed]): metrics per epoch")
     return p
 
 
@@ -75,10 +85,10 @@ def main(args):
 
     if not torch.cuda.is_available():
         raise RuntimeError("buffer.py needs an MI355X; the engine has no CPU path")
-    if not args.synthetic_data:
+    if not args.synthetic_data and not args.train_images:
         raise NotImplementedError(
-            "training experts on %s needs the dataset and BERT text embeddings, which are outside the "
-            "MI355X hot path (SURVEY 8f); pass --synthetic_data STEPS to exercise the pipeline" % args.dataset)
+            "no data source: pass --train_images FILE (+ the train-caption embedding cache in --embed_dir) "
+            "for real pairs, or --synthetic_data STEPS to exercise the pipeline on random pairs")
     device = torch.device("cuda")
     variant = VARIANTS[args.image_encoder]
     d_txt = 768 if args.text_encoder == "bert" else 512
@@ -91,6 +101,25 @@ def main(args):
     shapes_t = [s for _, s, _ in eng.param_table("txt")]
     g = torch.Generator(device=device).manual_seed(args.seed)
     from .optim import sgd_step
+    real = eval_set = eng_tail = None
+    if args.train_images:
+        from . import epoch as ep
+        from .embed_cache import load_embed_cache, load_eval_data, load_tensor_file
+        imgs = load_tensor_file(args.train_images, key="images").float()
+        emb = load_embed_cache(args, "train_text")
+        if imgs.shape[0] != emb.shape[0] or tuple(imgs.shape[1:]) != (3, args.image_size, args.image_size) \
+                or emb.shape[1] != d_txt:
+            raise ValueError("train images %s / caption embeddings %s do not form [M,3,%d,%d] x [M,%d] pairs"
+                             % (tuple(imgs.shape), tuple(emb.shape), args.image_size, args.image_size, d_txt))
+        real = (imgs.to(device).contiguous(), emb.to(device).contiguous())
+        tail = imgs.shape[0] % n
+        if tail >= 2:      # the reference's DataLoader also trains on the ragged last batch
+            eng_tail = UnrollEngine(variant, batch=tail, num_queries=tail, image_size=args.image_size, d_txt=d_txt,
+                                    syn_steps=1, dtype=args.compute_dtype, device=device)
+        if args.eval_data:
+            ti, te, i2t, t2i = load_eval_data(args.eval_data, args)
+            eval_set = (ti.to(device).contiguous(), te.to(device).contiguous(), i2t, t2i)
+        cpu_gen = torch.Generator().manual_seed(args.seed)
     for it in range(args.num_experts):
         th_i, th_t = synthetic_expert_params(eng, args.seed * 100003 + it, device=device)
         snaps_i, snaps_t = [th_i.cpu()], [th_t.cpu()]          # buffer.py:67-68
@@ -100,7 +129,17 @@ def main(args):
         first = True
         lr_schedule = [args.train_epochs // 2 + 1]             # buffer.py:70
         for e in range(args.train_epochs):
-            for _ in range(args.synthetic_data):
+            if real is not None:     # reference buffer.py:73-92: one pass over the training pairs, then metrics
+                train_loss, train_acc, first = ep.train_epoch(
+                    eng, th_i, th_t, mom_i, mom_t, real[0], real[1], lr_i, n, first, momentum=args.mom,
+                    weight_decay=args.l2, generator=cpu_gen, lr_txt=lr_t, eng_tail=eng_tail, with_accuracy=True)
+                msg = "Itr: {}\tEpoch: {}\tTrain Loss: {:.4f}\tTrain Acc: {:.4f}".format(it, e, train_loss, train_acc)
+                if eval_set is not None:
+                    r = ep.epoch_test_metrics(eng, th_i, th_t, *eval_set)
+                    msg += "\tImg R@1: {:.2f}\tR@5: {:.2f}\tR@10: {:.2f}\tTxt R@1: {:.2f}\tR@5: {:.2f}\tR@10: {:.2f}".format(
+                        r["img_r1"], r["img_r5"], r["img_r10"], r["txt_r1"], r["txt_r5"], r["txt_r10"])
+                print(msg)
+            for _ in range(args.synthetic_data if real is None else 0):
                 img = torch.randn(n, 3, args.image_size, args.image_size, device=device, generator=g)
                 txt = torch.randn(n, d_txt, device=device, generator=g) * 0.5253
                 x = eng.img_forward(0, th_i, img)
@@ -127,6 +166,8 @@ def main(args):
         save_expert_file(os.path.join(save_dir, "txt_replay_buffer_%d.pt" % k),
                          torch.stack(snaps_t)[None], shapes_t)
     eng.close()
+    if eng_tail is not None:
+        eng_tail.close()
 
 
 if __name__ == "__main__":

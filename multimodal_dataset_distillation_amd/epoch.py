@@ -99,29 +99,57 @@ def epoch_test_metrics(eng, theta_img, theta_txt, test_images, text_embeds, img2
     return recalls(r_i, r_t)
 
 
+def _train_accuracy(x, y):
+    """acc of reference CLIPModel_full.forward (networks.py:883-886): argmax hits in both directions / 2.
+    Logging only (a [B,B] product on B <= a few hundred rows); device tensor, no sync."""
+    xn, yn = x / x.norm(dim=1, keepdim=True), y / y.norm(dim=1, keepdim=True)
+    logits = xn @ yn.t()
+    gt = torch.arange(logits.shape[0], device=logits.device)
+    return ((logits.argmax(1) == gt).sum() + (logits.argmax(0) == gt).sum()).float() / 2
+
+
 def train_epoch(eng, theta_img, theta_txt, mom_img, mom_txt, images, texts, lr, batch, first,
-                momentum=0.9, weight_decay=5e-4, generator=None):
-    """One epoch of reference `epoch` (epoch.py:59-98) on (images, texts) with the optimisers of
-    evaluate_synset (epoch.py:361-362): SGD(momentum 0.9, weight_decay 5e-4), fixed logit scale 1/0.07,
-    shuffled mini-batches; in place on theta_*/mom_*.  Returns (mean loss, first-step flag)."""
+                momentum=0.9, weight_decay=5e-4, generator=None, lr_txt=None, eng_tail=None,
+                with_accuracy=False):
+    """One epoch of reference `epoch` (epoch.py:59-98): shuffled mini-batches of (image, caption embedding)
+    pairs, forward + fixed-scale (1/0.07) contrastive loss + backward + one SGD step per network
+    (`optim.sgd_step` = torch.optim.SGD(lr, momentum, weight_decay)); in place on theta_*/mom_*.
+    Defaults are evaluate_synset's optimisers (epoch.py:361-362); buffer.py passes --mom/--l2 and the two
+    teacher learning rates.  The engine's batch is fixed: a ragged last batch runs on `eng_tail` (an
+    engine of that batch size) when one is given and is dropped otherwise.  One host sync per epoch.
+    Returns (mean loss, first-step flag) or (mean loss, mean accuracy, first-step flag)."""
     from .optim import sgd_step
     n = images.shape[0]
     perm = torch.randperm(n, generator=generator).to(images.device)
-    loss_sum, seen = 0.0, 0
-    for s in range(0, n - batch + 1, batch):       # the engine's batch is fixed; a ragged tail is dropped
+    lr_t = lr if lr_txt is None else lr_txt
+    loss_sum = torch.zeros(1, device=images.device)
+    acc_sum = torch.zeros(1, device=images.device)
+    seen = 0
+    for s in range(0, n, batch):
         idx = perm[s:s + batch]
-        x = eng.img_forward(0, theta_img, images, idx=idx)
-        mask = (torch.rand(batch, eng.feature_dim, device=images.device) >= 0.1).float() / 0.9
-        y = eng.txt_forward(0, theta_txt, texts, idx=idx, drop_mask=mask)
-        loss, xb, yb, _ = eng.contrastive(x, y, LOGIT_SCALE)
-        gi = eng.img_backward(0, theta_img, xb)
-        gt = eng.txt_backward(0, theta_txt, yb)
-        for th, g, m in ((theta_img, gi, mom_img), (theta_txt, gt, mom_txt)):
-            sgd_step(th, g, m, lr, momentum, weight_decay, first)
+        e = eng
+        if idx.numel() < batch:
+            if eng_tail is None or eng_tail.batch != idx.numel():
+                break                                   # ragged tail without a matching engine: dropped
+            e = eng_tail
+        b = idx.numel()
+        x = e.img_forward(0, theta_img, images, idx=idx)
+        mask = (torch.rand(b, e.feature_dim, device=images.device) >= 0.1).float() / 0.9
+        y = e.txt_forward(0, theta_txt, texts, idx=idx, drop_mask=mask)
+        loss, xb, yb, _ = e.contrastive(x, y, LOGIT_SCALE)
+        gi = e.img_backward(0, theta_img, xb)
+        gt = e.txt_backward(0, theta_txt, yb)
+        sgd_step(theta_img, gi, mom_img, lr, momentum, weight_decay, first)
+        sgd_step(theta_txt, gt, mom_txt, lr_t, momentum, weight_decay, first)
         first = False
-        loss_sum += float(loss.item()) * batch
-        seen += batch
-    return (loss_sum / max(1, seen)), first
+        loss_sum += loss * b
+        if with_accuracy:
+            acc_sum += _train_accuracy(x, y)
+        seen += b
+    mean_loss = float(loss_sum.item()) / max(1, seen)
+    if with_accuracy:
+        return mean_loss, float(acc_sum.item()) / max(1, seen), first
+    return mean_loss, first
 
 
 def evaluate_synset(eng, image_syn, text_syn, test_images, text_embeds, img2txt, txt2img, lr_net=0.1,
