@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-launches", default=None,
                     help="CSV path: one row per contraction launch of the instrumented iteration")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo lets the N>1 code path "
+                         "be rehearsed with several ranks sharing one GPU)")
     ap.add_argument("--keep-steps", type=int, default=None,
                     help="activation stash policy (engine keep_steps): default keeps every step")
     ap.add_argument("--no-selfcheck", action="store_true",
@@ -129,13 +132,16 @@ def main():
         sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0)) % max(1, torch.cuda.device_count())
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.dist_backend)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -247,7 +253,8 @@ def main():
                        else args.workload,
                        "global_batch": n, "syn_steps": K,
                        "keep_steps": eng.keep_steps, "workspace_gib": eng.workspace_bytes / 2**30,
-                       "parallelism": "expert-replica x%d (1 all-reduce/step)" % world},
+                       "parallelism": "expert-replica x%d (1 all-reduce/step)" % world,
+                       "collective_backend": args.dist_backend if world > 1 else None},
             "grand_loss": losses[0], "grand_loss_per_rank": rank_losses,
             "grad_norms": gnorm,
             "sgd_lr_scale": SGD_LR_SCALE,
