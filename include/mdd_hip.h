@@ -64,6 +64,9 @@ typedef struct mdd_config {
 } mdd_config;
 
 const char* mdd_last_error(void);
+/* ABI version of this header: 2 = round 2 (mdd_config.keep_steps, MDD_DTYPE_BF16X2 / _F32_BF16OPS,
+ * profile kind 4).  A binding built against another version must refuse to load. */
+#define MDD_ABI_VERSION 2
 int mdd_version(void);
 
 /* ---- engine lifetime and memory (the caller owns device memory: PyTorch caching allocator) */

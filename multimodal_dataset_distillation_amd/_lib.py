@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmdd_hip.so")
 
 DTYPE_F32, DTYPE_BF16, DTYPE_BF16X2, DTYPE_F32_BF16OPS = 0, 1, 2, 3
+ABI_VERSION = 2     # include/mdd_hip.h MDD_ABI_VERSION
 
 
 class MddConfig(C.Structure):
@@ -87,6 +88,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args
+    if lib.mdd_version() != ABI_VERSION:      # MddConfig / MddIterArgs layouts below belong to this version
+        raise RuntimeError("libmdd_hip.so ABI version %d, this binding expects %d: rebuild (build_ext)"
+                           % (lib.mdd_version(), ABI_VERSION))
     _lib = lib
     return lib
 

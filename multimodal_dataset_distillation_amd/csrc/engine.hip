@@ -987,7 +987,7 @@ struct Eng : mdd_engine {
 extern "C" {
 
 const char* mdd_last_error(void) { return g_err.c_str(); }
-int mdd_version(void) { return 1; }
+int mdd_version(void) { return MDD_ABI_VERSION; }
 
 int mdd_engine_create(const mdd_config* cfg, mdd_engine** out) {
   CHECK_ARG(cfg && out && cfg->variant, "null config");

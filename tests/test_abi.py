@@ -27,6 +27,8 @@ def test_header_symbols_all_exported():
     assert declared == set(SIGNATURES), declared ^ set(SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
+    m = re.search(r"#define\s+MDD_ABI_VERSION\s+(\d+)", hdr)
+    assert m and lib.mdd_version() == int(m.group(1)) == _lib().ABI_VERSION
 
 
 @pytest.mark.parametrize("variant,expect", [("nfnet_l0", 32769488), ("nfnet_tiny", None)])
