@@ -172,7 +172,10 @@ def main():
     # student's move: grand_loss = 2 whatever the kernels do).
     from multimodal_dataset_distillation_amd.networks import student_move_normalised_targets
     tgi, tgt, sig_i, sig_t = student_move_normalised_targets(eng, th0i, th0t, image_syn, text_syn, lr, K, gt)
-    pg = torch.Generator().manual_seed(3)   # same permutations on every rank
+    # minibatch permutations (distill.py:510-511) are drawn ON THE DEVICE: a host randperm + pageable H2D copy is
+    # stream-ordered behind the previous iteration and made the host wait for it before it could enqueue the
+    # next one (4-5 ms of idle GPU per step).  Same seed -> same permutations on every rank.
+    pg = torch.Generator(device=dev).manual_seed(3)
     n_img, n_txt = image_syn.numel(), text_syn.numel()
     from multimodal_dataset_distillation_amd import parallel as par
     flat, views = par.fused_grad_buffer(image_syn, text_syn)   # one fused all-reduce buffer (+ NaN flag)
@@ -188,7 +191,7 @@ def main():
     step_no = [0]
 
     def one_step():
-        perms = torch.stack([torch.randperm(n, generator=pg) for _ in range(K)]).to(dev)
+        perms = torch.stack([torch.randperm(n, generator=pg, device=dev) for _ in range(K)])
         eng.unrolled_match(image_syn, text_syn, lr[0:1], lr[1:2], th0i, th0t, tgi, tgt, perms=perms,
                            out=out)
         if world > 1:
