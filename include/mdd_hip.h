@@ -145,6 +145,12 @@ int mdd_flat_sqdist(const float* a_dev, const float* b_dev, double* out_dev, int
                     void* stream);                             /* out[0] += sum (a-b)^2 */
 int mdd_flat_sgd_momentum(float* p_dev, const float* g_dev, float* buf_dev, float lr, float mom,
                           int first, int64_t n, void* stream);
+/* the same step, a no-op when skip_flag_dev[0] != 0: the reference leaves its loop on a NaN loss BEFORE the
+ * optimiser steps (distill.py:599-613); with the decision taken on the device the host can enqueue the next
+ * iteration without first reading this one's loss back */
+int mdd_flat_sgd_momentum_guarded(float* p_dev, const float* g_dev, float* buf_dev, float lr,
+                                  float mom, int first, int64_t n, const float* skip_flag_dev,
+                                  void* stream);
 
 /* ---- one whole outer iteration (reference distill.py:509-606) */
 typedef struct mdd_iter_args {

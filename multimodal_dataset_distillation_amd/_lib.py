@@ -58,6 +58,7 @@ SIGNATURES = {
     "mdd_flat_axpy": (_I, [_P, _P, _P, _P, _F, _L, _P]),
     "mdd_flat_sqdist": (_I, [_P, _P, _P, _L, _P]),
     "mdd_flat_sgd_momentum": (_I, [_P, _P, _P, _F, _F, _I, _L, _P]),
+    "mdd_flat_sgd_momentum_guarded": (_I, [_P, _P, _P, _F, _F, _I, _L, _P, _P]),
     "mdd_engine_profile": (_I, [_P, _I]),
     "mdd_engine_profile_read": (_I, [_P, _I, C.POINTER(C.c_double)]),
     "mdd_engine_profile_dump": (_I, [_P, C.c_char_p]),

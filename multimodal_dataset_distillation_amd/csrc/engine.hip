@@ -1144,8 +1144,15 @@ int mdd_flat_sqdist(const float* a, const float* b, double* out, int64_t n, void
 int mdd_flat_sgd_momentum(float* p, const float* g, float* buf, float lr, float mom, int first,
                           int64_t n, void* stream) {
   CHECK_ARG(p && g && buf && n >= 0, "null pointer");
-  launch_sgd_momentum(p, g, buf, lr, mom, first, n, (hipStream_t)stream);
+  launch_sgd_momentum(p, g, buf, lr, mom, first, n, nullptr, (hipStream_t)stream);
   POST_LAUNCH("sgd");
+  return 0;
+}
+int mdd_flat_sgd_momentum_guarded(float* p, const float* g, float* buf, float lr, float mom, int first,
+                                  int64_t n, const float* skip_flag, void* stream) {
+  CHECK_ARG(p && g && buf && skip_flag && n >= 0, "null pointer");
+  launch_sgd_momentum(p, g, buf, lr, mom, first, n, skip_flag, (hipStream_t)stream);
+  POST_LAUNCH("sgd_guarded");
   return 0;
 }
 int mdd_engine_profile(mdd_engine* e, int enable) {

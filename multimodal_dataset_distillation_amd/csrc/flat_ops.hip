@@ -122,7 +122,11 @@ __global__ void k_sub_inplace(float* __restrict__ y, const float* __restrict__ x
 
 // torch.optim.SGD(momentum=m, dampening=0): buf = g (first) | m*buf+g ; p -= lr*buf
 __global__ void k_sgd_momentum(float* __restrict__ p, const float* __restrict__ g,
-                               float* __restrict__ buf, float lr, float mom, int first, int64_t n) {
+                               float* __restrict__ buf, float lr, float mom, int first, int64_t n,
+                               const float* __restrict__ skip) {
+  // skip (optional, device): non-zero => the step is a no-op.  Lets the host enqueue the next iteration
+  // before it has read this one's NaN flag (reference distill.py:599 breaks BEFORE the optimiser steps).
+  if (skip != nullptr && skip[0] != 0.f) return;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
     float b = first ? g[i] : mom * buf[i] + g[i];
@@ -181,8 +185,8 @@ void launch_sub_inplace(float* y, const float* x, int64_t n, hipStream_t st) {
   k_sub_inplace<<<grid_for(n >> 2), kBlock, 0, st>>>(y, x, n);
 }
 void launch_sgd_momentum(float* p, const float* g, float* buf, float lr, float mom, int first,
-                         int64_t n, hipStream_t st) {
-  k_sgd_momentum<<<grid_for(n), kBlock, 0, st>>>(p, g, buf, lr, mom, first, n);
+                         int64_t n, const float* skip, hipStream_t st) {
+  k_sgd_momentum<<<grid_for(n), kBlock, 0, st>>>(p, g, buf, lr, mom, first, n, skip);
 }
 void launch_match_finalize(const double* s, float* out, hipStream_t st) {
   k_match_finalize<<<1, 64, 0, st>>>(s, out);

@@ -17,7 +17,7 @@ void launch_lambda_init(float* lam, const float* thK, const float* tgt, const do
                         int64_t n, hipStream_t st);
 void launch_sub_inplace(float* y, const float* x, int64_t n, hipStream_t st);
 void launch_sgd_momentum(float* p, const float* g, float* buf, float lr, float mom, int first,
-                         int64_t n, hipStream_t st);
+                         int64_t n, const float* skip, hipStream_t st);
 void launch_match_finalize(const double* s, float* out, hipStream_t st);
 void launch_d2f(float* out, const double* in, float mul, int accum, int n, hipStream_t st);
 void launch_accum_f2d(double* out, const float* in, double sign, hipStream_t st);

@@ -351,6 +351,8 @@ def main(args):
 
     P = lambda t: C.c_void_p(t.data_ptr())
     first_step = True
+    stopper = par.DeferredStop(device)
+    nan_at = None
     t_start = time.time()
     for it in range(args.Iteration + 1):
         # ---- evaluation block (distill.py:293-357), when a held-out set was supplied
@@ -401,31 +403,39 @@ def main(args):
             out["image_syn"].copy_(gi), out["text_syn"].copy_(gt_)
             out["lr"].copy_(torch.stack([gli, glt]))
             losses = torch.stack([grand.detach(), il.detach(), tl.detach()] + ces)
-        # NaN -> leave the loop (distill.py:599-600).  The decision is COLLECTIVE: the flag rides in the
-        # all-reduced buffer, so every rank sees the same value, breaks at the same iteration (a rank that
-        # left alone would pair its barrier with the others' next all-reduce) and nobody applies gradients
-        # that another rank's NaN poisoned.  One host sync per iteration.
-        stop = par.reduce_gradients_and_stop_flag_(flat, views, losses[:3], reduce=world > 1 and not mode_b)
-        lh = losses[:3].tolist()
-        if stop:
-            print("img_param_loss is NaN at iteration %d%s: stopping (reference distill.py:599)"
-                  % (it, "" if math.isnan(lh[1]) else " on another rank"))
-            break
+        # NaN -> leave the loop (distill.py:599-600).  The decision is COLLECTIVE (the flag rides in the
+        # all-reduced buffer: every rank sees the same value) and taken ON THE DEVICE: the optimiser steps
+        # below are guarded by the sticky flag, so nothing is applied from the NaN iteration on, and the host
+        # reads the flag one iteration late, after the next iteration has been enqueued -- no host
+        # synchronisation between iterations.
+        prev = stopper.update(flat, views, losses[:3], reduce=world > 1 and not mode_b, iteration=it)
         # ---- optimizer_lr / optimizer_img / optimizer_txt .step() (distill.py:233-241, 611-613)
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         for p, off, cnt, lrv in ((image_syn, 0, n_img, args.lr_img), (text_syn, n_img, n_txt, args.lr_txt),
                                  (lr, n_img + n_txt, 2, args.lr_lr)):
-            _lib.check(lib.mdd_flat_sgd_momentum(P(p), P(grads[off:off + cnt]), P(mom[off:off + cnt]),
-                                                 float(lrv), 0.5, 1 if first_step else 0, cnt, st))
+            _lib.check(lib.mdd_flat_sgd_momentum_guarded(P(p), P(grads[off:off + cnt]), P(mom[off:off + cnt]),
+                                                         float(lrv), 0.5, 1 if first_step else 0, cnt,
+                                                         P(stopper.sticky), st))
         first_step = False
-        if it % 10 == 0 and rank == 0:
-            print("%s iter = %04d, loss = %.4f (img %.4f txt %.4f) start_epoch=%d  %.2f it/s"
-                  % (time.strftime("[%Y-%m-%d %H:%M:%S]"), it, lh[0], lh[1], lh[2], start_epoch,
-                     (it + 1) / (time.time() - t_start)))
+        if prev is not None:
+            stop, pit, lh = stopper.read(prev)
+            if stop:
+                nan_at = pit
+                break
+            if pit % 10 == 0 and rank == 0:
+                print("%s iter = %04d, loss = %.4f (img %.4f txt %.4f)  %.2f it/s"
+                      % (time.strftime("[%Y-%m-%d %H:%M:%S]"), pit, lh[0], lh[1], lh[2],
+                         (pit + 1) / (time.time() - t_start)))
         if args.save_dir and rank == 0 and (it % max(1, args.save_interval * 10) == 0 or it == args.Iteration):
             os.makedirs(args.save_dir, exist_ok=True)
             torch.save({"image_syn": image_syn.cpu(), "text_syn": text_syn.cpu(), "syn_lr": lr.cpu(), "it": it},
                        os.path.join(args.save_dir, "distilled_%s.pt" % args.dataset))
+    if nan_at is None:
+        stop, pit, _ = stopper.last()
+        nan_at = pit if stop else None
+    if nan_at is not None:
+        print("img_param_loss is NaN at iteration %d: stopping (reference distill.py:599); the synthetic set "
+              "is the one before that iteration's update" % nan_at)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -41,6 +41,52 @@ def average_gradients_(flat, group=None):
     return flat
 
 
+class DeferredStop:
+    """The NaN break of reference distill.py:599-600 without a host synchronisation per iteration.
+
+    Every iteration: `update(flat, views, losses3, reduce)` writes this rank's NaN flag into the fused buffer,
+    all-reduces it with the gradients (mode A) and folds the REDUCED flag into a sticky device scalar
+    (`self.sticky`); the optimiser steps are enqueued GUARDED by that scalar (`mdd_flat_sgd_momentum_guarded`:
+    a no-op once it is non-zero), so the synthetic set stops changing at exactly the iteration the reference
+    would have left its loop at, on every rank.  The host learns about it one iteration later:
+    `poll()` returns (stop, iteration, losses) for the PREVIOUS update, whose device->host copy was queued
+    behind that iteration's work and has long finished when the next iteration has been enqueued.
+    """
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.sticky = torch.zeros(1, device=self.device)
+        pin = self.device.type == "cuda"
+        self._host = [torch.zeros(4, pin_memory=pin) for _ in range(2)]
+        self._event = [torch.cuda.Event() if pin else None for _ in range(2)]
+        self._pending = None
+        self._n = 0
+
+    def update(self, flat, views, losses3, reduce=True, group=None, iteration=None):
+        views["nan_flag"].copy_(torch.isnan(losses3).any().to(torch.float32).reshape(1))
+        if reduce:
+            average_gradients_(flat, group)
+        torch.maximum(self.sticky, (views["nan_flag"] > 0).to(torch.float32), out=self.sticky)
+        slot = self._n % 2
+        self._host[slot].copy_(torch.cat([self.sticky, losses3.reshape(3).to(torch.float32)]), non_blocking=True)
+        if self._event[slot] is not None:
+            self._event[slot].record()
+        prev, self._pending = self._pending, (slot, self._n if iteration is None else iteration)
+        self._n += 1
+        return prev
+
+    def read(self, pending):
+        """(stop, iteration, [grand, img, txt]) of a pending record (waits for ITS copy only)."""
+        slot, it = pending
+        if self._event[slot] is not None:
+            self._event[slot].synchronize()
+        h = self._host[slot].tolist()
+        return h[0] > 0, it, h[1:]
+
+    def last(self):
+        return self.read(self._pending) if self._pending is not None else (False, -1, [0.0, 0.0, 0.0])
+
+
 def expert_for_rank(iteration, rank, world, num_experts):
     """Rank r takes expert (iteration*world + r) mod E: the ranks of one iteration cover `world`
     consecutive experts of the reference's rotation (distill.py:450-465)."""

@@ -126,4 +126,12 @@ def test_flat_ops(report):
         _lib.check(lib.mdd_flat_sgd_momentum(P(p), P(gd), P(buf), 1000.0, 0.5, 0, n, st))
         ref_p = x - 1000.0 * g - 1000.0 * (0.5 * g + g)
         assert rel_err(p, ref_p) < 1e-6
+        # guarded step: a no-op (parameters AND momentum buffer) when the device flag is set
+        flag = torch.ones(1, device=dev)
+        p_before, buf_before = p.clone(), buf.clone()
+        _lib.check(lib.mdd_flat_sgd_momentum_guarded(P(p), P(gd), P(buf), 1000.0, 0.5, 0, n, P(flag), st))
+        assert torch.equal(p, p_before) and torch.equal(buf, buf_before)
+        flag.zero_()
+        _lib.check(lib.mdd_flat_sgd_momentum_guarded(P(p), P(gd), P(buf), 1000.0, 0.5, 0, n, P(flag), st))
+        assert rel_err(p, ref_p - 1000.0 * (0.5 * 1.5 * g + g)) < 1e-6
     report("flat_ops ok")

@@ -97,6 +97,49 @@ def test_nan_break_is_collective():
     assert out[0] == (2, 2) and out[1] == (2, 2)
 
 
+def _worker_deferred(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multimodal_dataset_distillation_amd import parallel as par
+    image_syn, text_syn = torch.zeros(2, 3, 4, 4), torch.zeros(2, 5)
+    flat, views = par.fused_grad_buffer(image_syn, text_syn)
+    stopper = par.DeferredStop("cpu")
+    state, applied, left_at, nan_seen = torch.zeros(1), [], None, None
+    for it in range(6):
+        views["grads"].fill_(1.0)
+        nan_here = rank == 1 and it == 2
+        losses = torch.tensor([float("nan")] * 3 if nan_here else [1.0 + it, 0.5, 0.5])
+        if nan_here:
+            views["grads"].fill_(float("nan"))
+        prev = stopper.update(flat, views, losses, iteration=it)
+        if stopper.sticky.item() == 0:          # what mdd_flat_sgd_momentum_guarded does on the device
+            state += views["grads"][0]
+            applied.append(it)
+        if prev is not None:
+            stop, pit, lh = stopper.read(prev)
+            if stop:
+                left_at, nan_seen = it, pit
+                break
+            assert lh[0] == 1.0 + pit or rank == 1      # rank 1's own losses may be the NaN ones later
+    dist.barrier()
+    out[rank] = (applied, left_at, nan_seen, float(state))
+    dist.destroy_process_group()
+
+
+def test_deferred_nan_stop_is_collective_and_freezes_the_state_at_the_nan_iteration():
+    """distill.py's loop without a host sync per iteration: the reduced NaN flag turns every later optimiser
+    step into a no-op on the device, the host notices one iteration later -- on every rank at the same
+    iteration, with the state of iteration 1 (the last finite one) intact."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_deferred, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        applied, left_at, nan_seen, state = out[r]
+        assert applied == [0, 1] and left_at == 3 and nan_seen == 2 and state == 2.0, out[r]
+
+
 def _toy_shard(rank, world, base):
     """A stand-in for parallel.sharded_unrolled_match with the same exchange protocol: gather the ranks'
     feature rows, reduce a rank-specific gradient, twice, and return what it was sent."""
