@@ -82,6 +82,114 @@ __global__ void k_img_scatter(float* __restrict__ dimage, const AT* __restrict__
   }
 }
 
+// ------------------------------------------------------------------ first stem conv: data gradient straight into d image
+// dimage[idx[n], c, y, x] += a * sum_{src} sum_{ty,tx,co} dy_src[n, (y+1-ty)/2, (x+1-tx)/2, co] * wt_src[c][ty*3+tx][co]
+// (3x3, stride 2, pad 1, 3 real input channels; a tap contributes only where its source coordinate is even and
+// inside: even y -> ty = 1, odd y -> ty in {0, 2}, the same in x).
+// The implicit-GEMM path spent 370 us on this layer per tangent pass (a 128x32 MFMA tile for 3 useful
+// columns, 16-byte stores on every other pixel of a parity class) plus 120 us to scatter its padded NHWC
+// result into the NCHW fp32 image gradient.  Here a 128-thread block owns 8 rows x 128 pixels of one image:
+// the 5 x 65 dy pixels those touch are brought into LDS in one batch of loads (both sources), each of the
+// two waves takes ONE x parity (row parity is a compile-time property of the unrolled row index), so only the
+// taps that hit are visited, with their 3 x COUT weights fetched once per tap (broadcast LDS reads) and reused
+// for the 4 rows they apply to.
+template <class AT, int COUT>
+__global__ __launch_bounds__(128, 4) void k_stem_dgrad_image(float* __restrict__ dimage, const AT* __restrict__ dy1,
+                                                          const AT* __restrict__ w1, const AT* __restrict__ dy2,
+                                                          const AT* __restrict__ w2, const int64_t* __restrict__ idx,
+                                                          const float* __restrict__ coef, float mul, int n, int s) {
+  constexpr int CE = Chunk<AT>::N, NCH = COUT / CE;
+  constexpr int PR = 5, PC = 65, NPIX = PR * PC;            // dy patch: rows y0/2 .. y0/2+4, cols x0/2 .. x0/2+64
+  __shared__ __attribute__((aligned(16))) float wsh[2][9][3][COUT];
+  __shared__ uint4 patch[2][NPIX * NCH];
+  const int tid = threadIdx.x, lane = tid & 63, xa = tid >> 6;
+  for (int i = tid; i < 2 * 27 * COUT; i += 128) {
+    const int src = i / (27 * COUT), r = i - src * 27 * COUT;
+    const int tap = r / (3 * COUT), c = (r / COUT) % 3, co = r % COUT;
+    const AT* w = src ? w2 : w1;
+    wsh[src][tap][c][co] = w ? to_f(w[((size_t)c * 9 + tap) * COUT + co]) : 0.f;   // wt layout [cin_pad][9][cout]
+  }
+  const int ho = s >> 1, spans = (s + 127) >> 7, yblocks = s >> 3;
+  int t = blockIdx.x;
+  const int xs = t % spans; t /= spans;
+  const int yb = t % yblocks;
+  const int ni = t / yblocks;
+  const int x0 = xs * 128, y0 = yb * 8, oy0 = y0 >> 1, ox0 = x0 >> 1;
+  // ---- patch -> LDS (zeros outside the dy tensor), every thread's loads issued before its LDS stores
+  constexpr int PER = (NPIX * NCH + 127) / 128;
+#pragma unroll
+  for (int src = 0; src < 2; ++src) {
+    const AT* dy = src ? dy2 : dy1;
+    if (dy == nullptr) continue;
+    uint4 r[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int ci = u * 128 + tid, pl = ci / NCH, k = ci - pl * NCH;
+      const int pr = pl / PC, pc = pl - pr * PC;
+      const bool ok = ci < NPIX * NCH && oy0 + pr < ho && ox0 + pc < ho;
+      r[u] = ok ? ((const uint4*)dy)[(((int64_t)ni * ho + oy0 + pr) * ho + ox0 + pc) * NCH + k] : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int ci = u * 128 + tid;
+      if (ci < NPIX * NCH) patch[src][ci] = r[u];
+    }
+  }
+  __syncthreads();
+  const int x = x0 + 2 * lane + xa;
+  float acc[8][3];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j][0] = acc[j][1] = acc[j][2] = 0.f;
+  const int ntx = xa ? 2 : 1;
+#pragma unroll
+  for (int src = 0; src < 2; ++src) {
+    if ((src ? dy2 : dy1) == nullptr) continue;                   // uniform
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+      for (int txi = 0; txi < ntx; ++txi) {                       // wave-uniform trip count
+        const int tx = xa ? 2 * txi : 1;
+        const int pc = ((x + 1 - tx) >> 1) - ox0;                 // 0..64; x + 1 - tx is even and >= 0 here
+        float w[3][COUT];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int co = 0; co < COUT; co += 4) {
+            const float4 v = *(const float4*)&wsh[src][ty * 3 + tx][c][co];
+            w[c][co] = v.x; w[c][co + 1] = v.y; w[c][co + 2] = v.z; w[c][co + 3] = v.w;
+          }
+        // rows y0 + j with (j + 1 - ty) even: even rows take ty == 1, odd rows ty in {0, 2}: four rows per tap;
+        // a source row above the tensor only occurs for y = 0, ty = 2 -> j + 1 - ty < 0
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int j = 2 * jj + ((ty + 1) & 1);
+          if (j + 1 - ty < 0) continue;                           // compile-time
+          const int pr = (j + 1 - ty) >> 1;                       // 0..4 (rows past the tensor were zero-filled)
+#pragma unroll
+          for (int k = 0; k < NCH; ++k) {
+            float v[CE];
+            Chunk<AT>::unpack(patch[src][(pr * PC + pc) * NCH + k], v);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+              acc[j][0] = fmaf(v[e], w[0][k * CE + e], acc[j][0]);
+              acc[j][1] = fmaf(v[e], w[1][k * CE + e], acc[j][1]);
+              acc[j][2] = fmaf(v[e], w[2][k * CE + e], acc[j][2]);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (x >= s) return;
+  const float a = mul * (coef ? coef[0] : 1.f);
+  const int64_t dst_n = idx ? idx[ni] : ni;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float* dst = dimage + (dst_n * 3) * (int64_t)s * s + (int64_t)(y0 + j) * s + x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dst[(int64_t)c * s * s] += a * acc[j][c];
+  }
+}
+
 // ------------------------------------------------------------------ AvgPool2d(2, stride, ceil_mode, count_include_pad=False)
 template <class AT>
 __global__ void k_avgpool2(AT* __restrict__ out, const AT* __restrict__ in, int n, int h, int w,
@@ -305,6 +413,18 @@ void launch_img_scatter_grad(float* dimage, const AT* x0bar, const int64_t* idx,
                                                                h, w, cpad);
 }
 template <class AT>
+bool launch_stem_dgrad_image(float* dimage, const AT* dy1, const AT* wt1, const AT* dy2, const AT* wt2,
+                             const int64_t* idx, const float* coef, float mul, int n, int s, int cout,
+                             int cpad, hipStream_t st) {
+  (void)cpad;
+  if ((s & 7) != 0) return false;
+  const int blocks = n * (s >> 3) * ((s + 127) >> 7);            // (image, 8-row block, 128-pixel span)
+  if (cout == 16) k_stem_dgrad_image<AT, 16><<<blocks, 128, 0, st>>>(dimage, dy1, wt1, dy2, wt2, idx, coef, mul, n, s);
+  else if (cout == 8) k_stem_dgrad_image<AT, 8><<<blocks, 128, 0, st>>>(dimage, dy1, wt1, dy2, wt2, idx, coef, mul, n, s);
+  else return false;     // other stem widths keep the implicit-GEMM path
+  return true;
+}
+template <class AT>
 void launch_avgpool2(AT* out, const AT* in, int n, int h, int w, int c, int stride,
                      hipStream_t st) {
   int ho = (h + stride - 1) / stride, wo = (w + stride - 1) / stride;
@@ -389,6 +509,9 @@ void launch_final_pool_bwd(AT* cfbar, AT* cfbar_t, const float* ybar, const floa
                                            int, hipStream_t);                                      \
   template void launch_img_scatter_grad<AT>(float*, const AT*, const int64_t*, const float*,       \
                                             float, int, int, int, int, int, hipStream_t);          \
+  template bool launch_stem_dgrad_image<AT>(float*, const AT*, const AT*, const AT*, const AT*,    \
+                                            const int64_t*, const float*, float, int, int, int,    \
+                                            int, hipStream_t);                                     \
   template void launch_avgpool2<AT>(AT*, const AT*, int, int, int, int, int, hipStream_t);         \
   template void launch_avgpool2_bwd<AT>(AT*, const AT*, int, int, int, int, int, hipStream_t);     \
   template void launch_pool_mean<AT>(float*, const AT*, int, int, int, hipStream_t);               \

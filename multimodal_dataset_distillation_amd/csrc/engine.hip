@@ -804,9 +804,19 @@ struct Eng : mdd_engine {
     conv_bwd_d(T, convs[stem[1]], O.CsB[1], Q.CsB[1],
                epi_act(T, O.AsB[0], O.CsB[0], Q.CsB[0], P.Cs[0], Q.Cs[0], 1.f, nullptr, nullptr), st);
     if (dimage) {
-      AT* x0b = T ? Q.X0B : O.X0B;
-      conv_bwd_d(T, convs[stem[0]], O.CsB[0], Q.CsB[0], epi_lin(x0b, nullptr), st);
-      launch_img_scatter_grad<AT>(dimage, x0b, idx, coef, mul, N, 3, S, S, 8, st);
+      const ConvL& L0 = convs[stem[0]];
+      // 3 real input channels: the image gradient is accumulated directly by a pixel-parallel kernel
+      // (tangent pass: dy_t (*) w + dy (*) w_t); other stem widths fall back to the implicit GEMM + scatter
+      const bool fused = L0.k == 3 && L0.stride == 2 && L0.pad == 1 && L0.cin == 3 && L0.groups == 1 &&
+                         launch_stem_dgrad_image<AT>(dimage, T ? Q.CsB[0] : O.CsB[0], wt + L0.off_p,
+                                                     T ? O.CsB[0] : (const AT*)nullptr,
+                                                     T ? wt_t + L0.off_p : (const AT*)nullptr, idx, coef, mul, N,
+                                                     S, L0.cout, L0.cin_pad, st);
+      if (!fused) {
+        AT* x0b = T ? Q.X0B : O.X0B;
+        conv_bwd_d(T, L0, O.CsB[0], Q.CsB[0], epi_lin(x0b, nullptr), st);
+        launch_img_scatter_grad<AT>(dimage, x0b, idx, coef, mul, N, 3, S, S, 8, st);
+      }
     }
     // the last two weight gradients run on the main stream: at this point the side stream still has
     // the high-resolution layers' weight gradients queued and would otherwise be waited for

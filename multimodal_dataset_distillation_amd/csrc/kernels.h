@@ -105,6 +105,14 @@ void launch_img_gather_nhwc(AT* x0, const float* image, const int64_t* idx, int 
 template <class AT>
 void launch_img_scatter_grad(float* dimage, const AT* x0bar, const int64_t* idx, const float* coef,
                              float mul, int n, int c, int h, int w, int cpad, hipStream_t st);
+// Data gradient of the FIRST stem conv (3x3, stride 2, pad 1, 3 real input channels) accumulated straight
+// into the NCHW fp32 image gradient: dimage[idx[n]] += coef*mul * (dy1 (*) wt1 + dy2 (*) wt2).
+// wt*: packed dgrad weights [cin_pad][9][cout].  Returns false when cout is not a supported width (the
+// caller then runs the implicit-GEMM data gradient + launch_img_scatter_grad).
+template <class AT>
+bool launch_stem_dgrad_image(float* dimage, const AT* dy1, const AT* wt1, const AT* dy2, const AT* wt2,
+                             const int64_t* idx, const float* coef, float mul, int n, int s, int cout,
+                             int cpad, hipStream_t st);
 template <class AT>
 void launch_avgpool2(AT* out, const AT* in, int n, int h, int w, int c, int stride, hipStream_t st);
 template <class AT>
