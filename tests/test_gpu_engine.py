@@ -355,3 +355,36 @@ def test_stash_policy_recompute_matches_keep_all_and_the_oracle(report):
     for keep in (0, 2, 3):
         d = max(rel_err(outs[keep][k], outs[None][k]) for k in outs[None])
         assert d < 1e-5, (keep, d)
+
+
+def test_unrolled_match_with_fewer_steps_than_the_engine_was_built_for(report):
+    """mdd_iter_args.syn_steps may be smaller than the engine's unroll depth (the workspace is planned for the
+    maximum): K=4 engine, 2-step call, with and without the recompute policy, against the 2-step oracle."""
+    from multimodal_dataset_distillation_amd.engine import UnrollEngine
+    from oracle import distill_ref as dr
+    n, size, d_txt, Kmax, Ks = 4, 64, 32, 4, 2
+    fi, ft = make_oracle("nfnet_tiny", d_txt, 41)
+    img, txt = dr.synthetic_inputs(n, size, d_txt, seed=14)
+    g = torch.Generator().manual_seed(9)
+    perms = [torch.randperm(n, generator=g) for _ in range(Ks)]
+    th0i, th0t = fi.flat_param(), ft.flat_param()
+    tgi = th0i + 2e-3 * torch.randn(th0i.shape, generator=g)
+    tgt = th0t + 2e-3 * torch.randn(th0t.shape, generator=g)
+    im, tx = img.clone().requires_grad_(True), txt.clone().requires_grad_(True)
+    lri = torch.tensor(0.1, requires_grad=True); lrt = torch.tensor(0.1, requires_grad=True)
+    grand, _ = dr.unrolled_match(fi, ft, im, tx, lri, lrt, th0i, th0t, tgi, tgt, perms)
+    gi, gt_, gli, glt = dr.outer_grads(grand, im, tx, lri, lrt)
+    dev = "cuda"
+    for keep in (None, 1):
+        eng = UnrollEngine("nfnet_tiny", batch=n, num_queries=n, image_size=size, d_txt=d_txt, syn_steps=Kmax,
+                           dtype="f32", keep_steps=keep)
+        lr = torch.tensor([0.1, 0.1], device=dev)
+        out = eng.unrolled_match(img.to(dev), txt.to(dev), lr[0:1], lr[1:2], th0i.to(dev), th0t.to(dev),
+                                 tgi.to(dev), tgt.to(dev), perms=torch.stack(perms).to(dev), syn_steps=Ks)
+        torch.cuda.synchronize()
+        e = dict(grand=abs(out["grand_loss"].item() - grand.item()) / abs(grand.item()),
+                 g_img=rel_err(out["image_syn"], gi), g_txt=rel_err(out["text_syn"], gt_),
+                 g_lr=rel_err(out["lr"], torch.stack([gli, glt])))
+        report(f"2-step call on a 4-step engine (keep_steps={keep}): " + " ".join(f"{k} {float(v):.2e}" for k, v in e.items()))
+        assert all(float(v) < 1e-3 for v in e.values()), (keep, e)
+        eng.close()
