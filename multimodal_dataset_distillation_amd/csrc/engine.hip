@@ -605,6 +605,15 @@ struct Eng : mdd_engine {
   // barrier packet on the main queue (~8-12 us bubble each), and nothing on the main stream waits for
   // these results before the end of the pass.
   static constexpr bool MAIN_TAIL = true;
+#ifndef MDD_FLUSH_EVERY
+#define MDD_FLUSH_EVERY 1        // release queued weight gradients to the side stream every this many blocks
+#endif
+#ifndef MDD_TAIL_MAIN
+#define MDD_TAIL_MAIN 2          // how many of the stem's weight gradients run on the main stream at the pass's tail
+#endif
+#ifndef MDD_FWD_SHORTCUT_SIDE
+#define MDD_FWD_SHORTCUT_SIDE 1  // forward passes: shortcut branch (avg-pool + 1x1 conv) on the side stream
+#endif
   std::vector<std::function<void(hipStream_t)>> wq;
   void flush_w(hipStream_t st, bool on_main = false) {
     if (wq.empty()) return;
@@ -675,7 +684,7 @@ struct Eng : mdd_engine {
         // the shortcut (avg-pool + 1x1 conv) only meets the residual branch at the SE apply: it runs on
         // the side stream, which is idle during forward passes
         hipStream_t ss = st;
-        if (use_side) { fork(st); ss = side; sc_forked = true; }
+        if (use_side && MDD_FWD_SHORTCUT_SIDE) { fork(st); ss = side; sc_forked = true; }
         const AT *din = a, *din_t = a_t;
         if (B.stride == 2) {
           launch_avgpool2<AT>(T ? qa.P : pa.P, T ? a_t : a, N, B.hin, B.hin, B.cin, 2, ss);
@@ -790,15 +799,17 @@ struct Eng : mdd_engine {
       conv_bwd_d(T, convs[B.c1], oa.C1B, qa.C1B,
                  epi_act(T, oa.AinB, O.XB[b], Q.XB[b], P.X[b], Q.X[b], B.beta, add1,
                          B.ds >= 0 ? nullptr : (T ? xb_t : xb)), st);
-      flush_w(st);
+      if (b == 0 || (nb - 1 - b) % MDD_FLUSH_EVERY == MDD_FLUSH_EVERY - 1) flush_w(st);
     }
     // stem (conv4 output is the raw stream X[0]; its grad is XB[0])
     conv_bwd_w(T, convs[stem[3]], O.XB[0], Q.XB[0], P.As[2], Q.As[2], dw, dw_t, gout, st);
     flush_w(st);   // stem: release each weight gradient at once (they are the tail of the pass)
     conv_bwd_d(T, convs[stem[3]], O.XB[0], Q.XB[0],
                epi_act(T, O.AsB[2], O.CsB[2], Q.CsB[2], P.Cs[2], Q.Cs[2], 1.f, nullptr, nullptr), st);
-    conv_bwd_w(T, convs[stem[2]], O.CsB[2], Q.CsB[2], P.As[1], Q.As[1], dw, dw_t, gout, st);
-    flush_w(st);   // stem: release each weight gradient at once (they are the tail of the pass)
+    if (MDD_TAIL_MAIN < 3) {
+      conv_bwd_w(T, convs[stem[2]], O.CsB[2], Q.CsB[2], P.As[1], Q.As[1], dw, dw_t, gout, st);
+      flush_w(st);   // stem: release each weight gradient at once (they are the tail of the pass)
+    }
     conv_bwd_d(T, convs[stem[2]], O.CsB[2], Q.CsB[2],
                epi_act(T, O.AsB[1], O.CsB[1], Q.CsB[1], P.Cs[1], Q.Cs[1], 1.f, nullptr, nullptr), st);
     conv_bwd_d(T, convs[stem[1]], O.CsB[1], Q.CsB[1],
@@ -820,6 +831,7 @@ struct Eng : mdd_engine {
     }
     // the last two weight gradients run on the main stream: at this point the side stream still has
     // the high-resolution layers' weight gradients queued and would otherwise be waited for
+    if (MDD_TAIL_MAIN >= 3) conv_bwd_w(T, convs[stem[2]], O.CsB[2], Q.CsB[2], P.As[1], Q.As[1], dw, dw_t, gout, st);
     conv_bwd_w(T, convs[stem[1]], O.CsB[1], Q.CsB[1], P.As[0], Q.As[0], dw, dw_t, gout, st);
     conv_bwd_w(T, convs[stem[0]], O.CsB[0], Q.CsB[0], P.X0, nullptr, dw, dw_t, gout, st);
     flush_w(st, MAIN_TAIL);
