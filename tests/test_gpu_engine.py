@@ -388,3 +388,38 @@ def test_unrolled_match_with_fewer_steps_than_the_engine_was_built_for(report):
         report(f"2-step call on a 4-step engine (keep_steps={keep}): " + " ".join(f"{k} {float(v):.2e}" for k, v in e.items()))
         assert all(float(v) < 1e-3 for v in e.values()), (keep, e)
         eng.close()
+
+
+def test_nfnet_l1_topology_matches_the_oracle(report):
+    """BASELINE config 4's image encoder (the l0 recipe at depths (2,4,12,6), feat_mult 2 -> 3072 features;
+    build-defined: timm 0.6.7 has no plain nfnet_l1 and the reference no working path for it) on a small
+    instance: one unrolled step + outer gradients in f32 mode against the oracle's nfnet_l1."""
+    from multimodal_dataset_distillation_amd.engine import UnrollEngine
+    from oracle import distill_ref as dr
+    n, size, d_txt, K = 4, 64, 48, 1
+    fi, ft = make_oracle("nfnet_l1", d_txt, 51)
+    assert ft.module.fc.out_features == 3072
+    img, txt = dr.synthetic_inputs(n, size, d_txt, seed=15)
+    g = torch.Generator().manual_seed(10)
+    perms = [torch.randperm(n, generator=g) for _ in range(K)]
+    th0i, th0t = fi.flat_param(), ft.flat_param()
+    tgi = th0i + 1e-3 * torch.randn(th0i.shape, generator=g)
+    tgt = th0t + 1e-3 * torch.randn(th0t.shape, generator=g)
+    im, tx = img.clone().requires_grad_(True), txt.clone().requires_grad_(True)
+    lri = torch.tensor(0.1, requires_grad=True); lrt = torch.tensor(0.1, requires_grad=True)
+    grand, info = dr.unrolled_match(fi, ft, im, tx, lri, lrt, th0i, th0t, tgi, tgt, perms)
+    gi, gt_, gli, glt = dr.outer_grads(grand, im, tx, lri, lrt)
+    dev = "cuda"
+    eng = UnrollEngine("nfnet_l1", batch=n, num_queries=n, image_size=size, d_txt=d_txt, syn_steps=K, dtype="f32")
+    assert eng.P_img == th0i.numel() and eng.feature_dim == 3072
+    lr = torch.tensor([0.1, 0.1], device=dev)
+    out = eng.unrolled_match(img.to(dev), txt.to(dev), lr[0:1], lr[1:2], th0i.to(dev), th0t.to(dev),
+                             tgi.to(dev), tgt.to(dev), perms=torch.stack(perms).to(dev))
+    torch.cuda.synchronize()
+    e = dict(grand=abs(out["grand_loss"].item() - grand.item()) / abs(grand.item()),
+             ces=rel_err(out["contrastive"], torch.stack(info["contrastive"])),
+             g_img=rel_err(out["image_syn"], gi), g_txt=rel_err(out["text_syn"], gt_),
+             g_lr=rel_err(out["lr"], torch.stack([gli, glt])))
+    report(f"nfnet_l1 ({eng.P_img} params, 3072 features) N={n} @{size}: " + " ".join(f"{k} {float(v):.2e}" for k, v in e.items()))
+    assert all(float(v) < 1e-3 for v in e.values()), e
+    eng.close()
