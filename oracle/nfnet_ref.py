@@ -13,7 +13,7 @@ restatement of timm 0.6.7's published ``NormFreeNet`` (``timm/models/nfnet.py``)
 ``ScaledStdConv2d`` (``timm/models/layers/std_conv.py``) algorithm.
 
 PARITY UNPINNED for the image encoder: the reference holds no test, golden vector or known-answer
-value at this boundary.  Structural anchors that ARE checked (tests/test_oracle_nfnet.py):
+value at this boundary.  Structural anchors that ARE checked (tests/test_oracle.py, tests/test_abi.py):
 feature dim 2304 (networks.py:811), 32,769,488 parameters without a head (35,074,488 with the
 1000-way head = timm's published 35.07 M), parameter order (weight, bias, gain) per conv.
 
