@@ -63,10 +63,13 @@ def test_real_init_decode_and_eval_hook(report, tmp_path, capsys):
     nw.release_engines()
 
 
-def test_mode_a_two_ranks_on_one_gpu_with_the_engine_in_the_loop(report, tmp_path):
-    """torch.distributed.run, 2 ranks, gloo (RCCL refuses two ranks on one device): every rank runs the
-    fused engine on its own synthetic expert, the fused [grads | NaN flag] buffer is all-reduced, and both
-    ranks must end with the identical synthetic set (saved by rank 0 and rank 1 separately)."""
+@pytest.mark.parametrize("mode", ["A", "B"])
+def test_two_ranks_on_one_gpu_with_the_engine_in_the_loop(mode, report, tmp_path):
+    """torch.distributed.run, 2 ranks, gloo (RCCL refuses two ranks on one device).
+    mode A: every rank runs the fused engine on its own synthetic expert, the fused [grads | NaN flag] buffer
+    is all-reduced; mode B (`--distributed`, the reference flag's meaning): every rank runs the unrolled loop
+    on its half of each minibatch, features all-gathered and gradients all-reduced inside the loop.
+    Both ranks must end with the identical synthetic set (saved by rank 0 and rank 1 separately)."""
     script = os.path.join(tmp_path, "run_rank.py")
     with open(script, "w") as f:
         f.write(
@@ -76,20 +79,20 @@ def test_mode_a_two_ranks_on_one_gpu_with_the_engine_in_the_loop(report, tmp_pat
             "argv = ['--image_encoder','nfnet_tiny','--num_queries','4','--mini_batch_size','4','--syn_steps','2',\n"
             "        '--expert_epochs','1','--max_start_epoch','2','--Iteration','2','--image_size','64',\n"
             "        '--lr_img','0.5','--lr_txt','0.5','--lr_lr','1e-5','--synthetic_experts','3','4',\n"
-            "        '--compute_dtype','f32','--dist_backend','gloo','--seed','5']\n"
+            "        '--compute_dtype','f32','--dist_backend','gloo','--seed','5'] + %r\n"
             "args, _ = distill.build_parser().parse_known_args(argv)\n"
             "torch.manual_seed(0)\n"
             "img, txt, lr = distill.main(args)\n"
             "torch.save({'img': img.cpu(), 'txt': txt.cpu(), 'lr': lr.cpu()}, os.path.join(%r, 'rank%%s.pt' %% os.environ['RANK']))\n"
-            % (ROOT, str(tmp_path)))
+            % (ROOT, ["--distributed"] if mode == "B" else [], str(tmp_path)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29617", script],
+                        "--master-addr", "127.0.0.1", "--master-port", "29617" if mode == "A" else "29618", script],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     a = torch.load(os.path.join(tmp_path, "rank0.pt"), weights_only=True)
     b = torch.load(os.path.join(tmp_path, "rank1.pt"), weights_only=True)
     for k in a:
         assert torch.isfinite(a[k]).all() and torch.equal(a[k], b[k]), k       # identical update on every rank
-    report("mode A, 2 ranks x engine on one GPU (gloo): identical synthetic set on both ranks, |img| %.4f"
-           % a["img"].norm().item())
+    report("mode %s, 2 ranks x engine on one GPU (gloo): identical synthetic set on both ranks, |img| %.4f"
+           % (mode, a["img"].norm().item()))
