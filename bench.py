@@ -40,7 +40,7 @@ KIND_NAMES = ["conv_gemm<128x32>", "conv_gemm<256x64>", "conv_gemm<128x128>", "c
 TRAFFIC_FILES = ["traffic_r02.json", "traffic_r01.json"]      # newest first
 # Budget for the post-timing self-check: relative error of the benched mode's outer gradients against ONE
 # f32-mode (exact-fp32 MFMA) iteration on the same inputs.  ~2x the errors measured on MI355X.
-SELFCHECK_BUDGET = {"bf16": dict(grand=5e-3, g_img=1e-1, g_txt=6e-2, g_lr=2e-2),
+SELFCHECK_BUDGET = {"bf16": dict(grand=5e-3, g_img=1e-1, g_txt=9e-2, g_lr=2e-2),
                     "bf16x2": dict(grand=1e-4, g_img=3e-3, g_txt=3e-3, g_lr=1e-3),
                     "f32": dict(grand=1e-5, g_img=1e-4, g_txt=1e-4, g_lr=1e-4)}
 
