@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 # f32 / bf16x2: the north_star bar.  bf16: ~2x the errors measured on MI355X for these miniature cases
 # (single-bf16 operands through two derivative orders; gpurun_out/test_report.txt)
-TOL = {"f32": 1e-3, "bf16x2": 1e-3, "bf16": 6e-2}
+TOL = {"f32": 1e-3, "bf16x2": 1e-3, "bf16": 8e-2}
 
 
 def make_oracle(variant, d_txt, seed):
