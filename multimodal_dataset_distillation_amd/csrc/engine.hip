@@ -412,10 +412,27 @@ struct Eng : mdd_engine {
   }
   int64_t workspace_bytes() const override { return ws_bytes; }
 
+  // The engine belongs to the device its workspace lives on: every entry point makes that device current for
+  // the duration of the call (a caller that drives several GPUs from one process, as the reference's
+  // nn.DataParallel path does, may arrive with another device current) and restores the caller's afterwards.
+  int device_id = -1;
+  struct DevGuard {
+    int prev = -1, want;
+    explicit DevGuard(int d) : want(d) {
+      if (d >= 0 && hipGetDevice(&prev) == hipSuccess && prev != d) (void)hipSetDevice(d); else prev = -1;
+    }
+    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  };
   int bind(void* ws, int64_t bytes, hipStream_t st) override {
     CHECK_ARG(ws != nullptr, "workspace is null");
     CHECK_ARG(bytes >= ws_bytes, "workspace too small");
     CHECK_ARG(((uintptr_t)ws & 255) == 0, "workspace must be 256-byte aligned");
+    {
+      hipPointerAttribute_t attr;
+      HIP_CHECK_RET(hipPointerGetAttributes(&attr, ws));
+      device_id = attr.device;
+    }
+    DevGuard guard(device_id);
     base = (char*)ws;
     for (auto& f : fix) *f.first = (void*)(base + f.second);
     d_descs = (WsDesc*)(base + o_descs);
@@ -660,6 +677,7 @@ struct Eng : mdd_engine {
   int img_forward(bool T, int slot, const float* th, const float* th_t, const float* image,
                   const int64_t* idx, float* feat_out, hipStream_t st) override {
     CHECK_ARG(base, "workspace not bound");
+    DevGuard guard(device_id);
     CHECK_ARG(slot >= 0 && slot < nslots, "slot out of range");
     ActSet& P = sets[slot]; ActSet& Q = tn;
     int nb = (int)blks.size();
@@ -726,6 +744,7 @@ struct Eng : mdd_engine {
                    const float* ybar_t_in, float* gout, float* dimage, const int64_t* idx,
                    const float* coef, float mul, bool repack, bool stash, hipStream_t st) override {
     CHECK_ARG(base, "workspace not bound");
+    DevGuard guard(device_id);
     CHECK_ARG(slot >= 0 && slot < nslots, "slot out of range");
     ActSet& P = sets[slot]; ActSet& Q = tn;
     ActSet& O = (!T && !stash) ? tn : P;  // where primal backward signals are written
@@ -846,6 +865,7 @@ struct Eng : mdd_engine {
   int txt_forward(bool T, int slot, const float* th, const float* th_t, const float* text,
                   const int64_t* idx, const float* mask, float* feat_out, hipStream_t st) override {
     CHECK_ARG(base, "workspace not bound");
+    DevGuard guard(device_id);
     CHECK_ARG(slot >= 0 && slot < nslots, "slot out of range");
     ActSet& P = sets[slot]; ActSet& Q = tn;
     if (!T) launch_gather_rows(P.tx, text, idx, N, Dt, st);
@@ -871,6 +891,7 @@ struct Eng : mdd_engine {
                    const float* ybar_t_in, float* gout, float* dtext, const int64_t* idx,
                    const float* coef, float mul, bool stash, hipStream_t st) override {
     CHECK_ARG(base, "workspace not bound");
+    DevGuard guard(device_id);
     CHECK_ARG(slot >= 0 && slot < nslots, "slot out of range");
     ActSet& P = sets[slot]; ActSet& Q = tn;
     ActSet& O = (!T && !stash) ? tn : P;
@@ -902,6 +923,7 @@ struct Eng : mdd_engine {
                   const float* scale_dev, float scale_const, float* loss, float* xb, float* yb,
                   float* sb, hipStream_t st) override {
     CHECK_ARG(base, "workspace not bound");
+    DevGuard guard(device_id);
     LossWork w = loss_work_carve(lossw, N, feat);
     if (!T) launch_contrastive(w, loss, xb, yb, sb, nullptr, nullptr, nullptr, x, y, nullptr,
                                nullptr, scale_dev, scale_const, N, feat, st);
@@ -914,6 +936,7 @@ struct Eng : mdd_engine {
   // ------------------------------------------------------------------ whole outer iteration
   int unrolled_match(const mdd_iter_args* a, hipStream_t st) override {
     CHECK_ARG(base, "workspace not bound");
+    DevGuard guard(device_id);
     CHECK_ARG(a->syn_steps >= 1 && a->syn_steps <= K, "syn_steps exceeds the engine's slots");
     const int Ks = a->syn_steps;
     const float* scale_dev = a->use_lr_as_scale ? a->lr_img : nullptr;
