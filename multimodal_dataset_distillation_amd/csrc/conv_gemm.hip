@@ -39,6 +39,11 @@
 #define MDD_MIN_WAVES 3
 #endif
 
+#ifndef MDD_SPLIT_3TERM
+#define MDD_SPLIT_3TERM 1   // bf16x2 K loop of the 2x2-wave instances: hh + hl + lh on register-regrouped chunk pairs
+                            // (0: hh + ll + hl + lh everywhere)
+#endif
+
 namespace {
 
 typedef unsigned __attribute__((ext_vector_type(4))) u32x4;   // first-class 16-byte register value
@@ -100,6 +105,20 @@ struct MmaSplit {
     bf16x8 av = __builtin_bit_cast(bf16x8, a);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, bs), acc, 0, 0, 0);
+  }
+  // Two chunks of each operand at once (eight K positions per lane): regrouping their registers as
+  // [h0..h7] and [l0..l7] costs no instruction and lets the ll term (below 2^-16 relative) be dropped:
+  // hh + hl + lh = three MFMAs per eight K positions instead of four.
+  static DEVI void step2(const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1, f32x16& acc) {
+    u32x4 ah, al, bh, bl;
+    ah[0] = a0[0]; ah[1] = a0[1]; ah[2] = a1[0]; ah[3] = a1[1];
+    al[0] = a0[2]; al[1] = a0[3]; al[2] = a1[2]; al[3] = a1[3];
+    bh[0] = b0[0]; bh[1] = b0[1]; bh[2] = b1[0]; bh[3] = b1[1];
+    bl[0] = b0[2]; bl[1] = b0[3]; bl[2] = b1[2]; bl[3] = b1[3];
+    const bf16x8 ahv = __builtin_bit_cast(bf16x8, ah), bhv = __builtin_bit_cast(bf16x8, bh);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahv, bhv, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahv, __builtin_bit_cast(bf16x8, bl), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), bhv, acc, 0, 0, 0);
   }
 };
 template <class AT, int PREC> struct MmaSel { typedef Mma<AT> type; };
@@ -453,6 +472,25 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
 #pragma unroll
         for (int j = 0; j < TN; ++j) MT::step(af[q & 1][i], bf[q & 1][j], acc[i][j]);
       __builtin_amdgcn_sched_barrier(0);
+    }
+    } else if constexpr (PREC == 1 && MDD_SPLIT_3TERM && WGM == 2) {
+    // bf16x2, 2x2-wave instances: the fragments of two K-slices at once, three MFMAs per pair (step2).  The
+    // 4x1-wave instances keep one slice at a time: the second fragment set does not fit their 168 registers
+    // (measured: 256x64 class 144 -> 191 ms per C2 iteration with it, 128x128 class 190 -> 170 ms).
+#pragma unroll
+    for (int q = 0; q < 4; q += 2) {
+      u32x4 af[2][TM], bf[2][TN];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[h][i] = *(const u32x4*)(smem + rdA[q + h] + i * 4096);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[h][j] = *(const u32x4*)(smem + rdB[q + h] + j * 4096);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) MT::step2(af[0][i], af[1][i], bf[0][j], bf[1][j], acc[i][j]);
     }
     } else {
 #pragma unroll
