@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo lets the N>1 code path "
                          "be rehearsed with several ranks sharing one GPU)")
+    ap.add_argument("--collective", default="torch", choices=["torch", "library"],
+                    help="who issues the per-step all-reduce at N>1: torch.distributed (default) or libmdd_hip.so's "
+                         "own RCCL communicator (mdd_allreduce_syn_grads; needs GPUs RCCL can pair, one per rank)")
     ap.add_argument("--keep-steps", type=int, default=None,
                     help="activation stash policy (engine keep_steps): default keeps every step")
     ap.add_argument("--no-selfcheck", action="store_true",
@@ -183,6 +186,7 @@ def main():
     out = dict(image_syn=views["image_syn"], text_syn=views["text_syn"], lr=views["lr"],
                losses=torch.zeros(3 + K, device=dev))
     mom = torch.zeros_like(flat_grad)
+    libcoll = par.LibraryCollective(dev) if (world > 1 and args.collective == "library") else None
     SGD_LR_SCALE = 1e-6
     ar_events = []          # (start, end) HIP events around each all-reduce (current stream)
     params = [(image_syn, 0, n_img, 1000.0), (text_syn, n_img, n_txt, 1000.0),
@@ -197,8 +201,11 @@ def main():
         if world > 1:
             ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ea.record()
-            dist.all_reduce(flat)        # RCCL; gradients + the collective NaN flag in one message
-            flat.div_(world)
+            if libcoll is not None:
+                libcoll.all_reduce_mean_(flat)   # the library's own RCCL communicator, this stream
+            else:
+                dist.all_reduce(flat)        # RCCL; gradients + the collective NaN flag in one message
+                flat.div_(world)
             eb.record()
             ar_events.append((ea, eb))
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -257,7 +264,8 @@ def main():
                        "global_batch": n, "syn_steps": K,
                        "keep_steps": eng.keep_steps, "workspace_gib": eng.workspace_bytes / 2**30,
                        "parallelism": "expert-replica x%d (1 all-reduce/step)" % world,
-                       "collective_backend": args.dist_backend if world > 1 else None},
+                       "collective_backend": args.dist_backend if world > 1 else None,
+                       "collective_issued_by": (args.collective if world > 1 else None)},
             "grand_loss": losses[0], "grand_loss_per_rank": rank_losses,
             "grad_norms": gnorm,
             "sgd_lr_scale": SGD_LR_SCALE,

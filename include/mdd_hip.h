@@ -65,8 +65,9 @@ typedef struct mdd_config {
 
 const char* mdd_last_error(void);
 /* ABI version of this header: 2 = round 2 (mdd_config.keep_steps, MDD_DTYPE_BF16X2 / _F32_BF16OPS,
- * profile kind 4).  A binding built against another version must refuse to load. */
-#define MDD_ABI_VERSION 2
+ * profile kind 4); 3 = + mdd_comm_* / mdd_allreduce_syn_grads.  A binding built against another version
+ * must refuse to load. */
+#define MDD_ABI_VERSION 3
 int mdd_version(void);
 
 /* ---- engine lifetime and memory (the caller owns device memory: PyTorch caching allocator) */
@@ -212,6 +213,23 @@ int mdd_retrieval_ranks(const float* img_feat, const float* txt_feat, const int*
  * matrix); norm_ws n_query+n_bank floats; idx_out [n_query].  All device memory. */
 int mdd_nearest_neighbor(const float* query, const float* bank, int n_query, int n_bank, int dim,
                          float* scores_ws, float* norm_ws, int* idx_out, void* stream);
+
+/* ---- RCCL all-reduce of the synthetic-set gradient (SURVEY 8b `allreduce_syn_grads`; mode A's one exchange
+ * per outer iteration -- north_star: "RCCL all-reduce of the matching-loss gradient over xGMI").  The reference
+ * has no counterpart (its only multi-GPU code is nn.DataParallel, distill.py:443-445).  RCCL is bound at run
+ * time from the librccl.so.1 the process already holds (torch's), else /opt/rocm's; every entry fails with
+ * "mdd: RCCL unavailable" when there is none.  One communicator per rank = per GPU:
+ *   rank 0: mdd_comm_unique_id(id)  ->  the host moves the MDD_COMM_ID_BYTES to every rank (any channel)
+ *   all   : mdd_comm_create(id, rank, world, device_id, &c)          (collective: returns when all joined)
+ *   all   : mdd_allreduce_syn_grads(c, buf, n, average, stream)      (in place, fp32 sum; average != 0 then
+ *           divides by world in the same stream order: bit-identical to all_reduce(SUM) + div_(world)) */
+#define MDD_COMM_ID_BYTES 128
+typedef struct mdd_comm mdd_comm;
+int mdd_comm_unique_id(void* id_out);
+int mdd_comm_create(const void* id, int rank, int world, int device_id, mdd_comm** out);
+void mdd_comm_destroy(mdd_comm* c);
+int mdd_comm_world(const mdd_comm* c);
+int mdd_allreduce_syn_grads(mdd_comm* c, float* buf_dev, int64_t n, int average, void* stream);
 
 #ifdef __cplusplus
 }

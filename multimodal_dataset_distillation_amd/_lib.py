@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmdd_hip.so")
 
 DTYPE_F32, DTYPE_BF16, DTYPE_BF16X2, DTYPE_F32_BF16OPS = 0, 1, 2, 3
-ABI_VERSION = 2     # include/mdd_hip.h MDD_ABI_VERSION
+ABI_VERSION = 3     # include/mdd_hip.h MDD_ABI_VERSION
 
 
 class MddConfig(C.Structure):
@@ -69,7 +69,13 @@ SIGNATURES = {
     "mdd_op_contrastive": (_I, [_I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P]),
     "mdd_retrieval_ranks": (_I, [_P] * 5 + [_I] * 3 + [C.c_float] + [_P] * 5),
     "mdd_nearest_neighbor": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "mdd_comm_unique_id": (_I, [_P]),
+    "mdd_comm_create": (_I, [_P, _I, _I, _I, C.POINTER(_P)]),
+    "mdd_comm_destroy": (None, [_P]),
+    "mdd_comm_world": (_I, [_P]),
+    "mdd_allreduce_syn_grads": (_I, [_P, _P, _L, _I, _P]),
 }
+COMM_ID_BYTES = 128   # include/mdd_hip.h MDD_COMM_ID_BYTES
 
 _lib = None
 

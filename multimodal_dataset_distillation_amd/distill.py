@@ -117,6 +117,9 @@ def build_parser():
     p.add_argument("--dist_backend", default="nccl", choices=["nccl", "gloo"],
                    help="torch.distributed backend under a launcher (nccl = RCCL; gloo lets several "
                         "ranks share one GPU in tests)")
+    p.add_argument("--collective", default="torch", choices=["torch", "library"],
+                   help="mode A's all-reduce issued by torch.distributed (default) or by libmdd_hip.so's own "
+                        "RCCL communicator (mdd_allreduce_syn_grads)")
     p.add_argument("--embed_dir", type=str, default=".",
                    help="directory of the {dataset}_{text_encoder}_{text,train_text}_embed.npz caches "
                         "(reference utils.py:885 reads them from the working directory)")
@@ -352,6 +355,7 @@ def main(args):
     P = lambda t: C.c_void_p(t.data_ptr())
     first_step = True
     stopper = par.DeferredStop(device)
+    coll = par.LibraryCollective(device) if (world > 1 and not mode_b and args.collective == "library") else None
     nan_at = None
     t_start = time.time()
     for it in range(args.Iteration + 1):
@@ -408,7 +412,7 @@ def main(args):
         # below are guarded by the sticky flag, so nothing is applied from the NaN iteration on, and the host
         # reads the flag one iteration late, after the next iteration has been enqueued -- no host
         # synchronisation between iterations.
-        prev = stopper.update(flat, views, losses[:3], reduce=world > 1 and not mode_b, iteration=it)
+        prev = stopper.update(flat, views, losses[:3], reduce=world > 1 and not mode_b, group=coll, iteration=it)
         # ---- optimizer_lr / optimizer_img / optimizer_txt .step() (distill.py:233-241, 611-613)
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         for p, off, cnt, lrv in ((image_syn, 0, n_img, args.lr_img), (text_syn, n_img, n_txt, args.lr_txt),

@@ -34,11 +34,63 @@ def reduce_gradients_and_stop_flag_(flat, views, losses3, reduce=True, group=Non
 
 
 def average_gradients_(flat, group=None):
-    """In-place mean over ranks; no-op for a single process."""
+    """In-place mean over ranks; no-op for a single process.  `group` is a torch.distributed process group
+    (or None = the default one) or a `LibraryCollective` (the library's own RCCL communicator)."""
+    if isinstance(group, LibraryCollective):
+        return group.all_reduce_mean_(flat)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         flat.div_(dist.get_world_size(group))
     return flat
+
+
+class LibraryCollective:
+    """Mode A's all-reduce issued by libmdd_hip.so itself (`mdd_allreduce_syn_grads`, include/mdd_hip.h) on an
+    RCCL communicator the library owns, in the caller's stream: no hop through torch's NCCL stream.
+    torch.distributed (any backend) is used ONCE, to carry rank 0's 128-byte RCCL unique id to the other ranks;
+    with no process group initialised the communicator has the single rank 0.  Same result as
+    `all_reduce(SUM)` + `div_(world)`.  There is no fallback: without RCCL the constructor raises."""
+
+    def __init__(self, device, group=None):
+        import ctypes as C
+        from . import _lib
+        self._lib_mod, self._lib = _lib, _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("LibraryCollective needs a GPU: RCCL has no CPU path")
+        multi = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if multi else 0
+        self.world = dist.get_world_size(group) if multi else 1
+        uid = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
+        if self.rank == 0:
+            _lib.check(self._lib.mdd_comm_unique_id(C.c_void_p(uid.data_ptr())))
+        if self.world > 1:
+            carrier = uid.to(self.device) if dist.get_backend(group) == "nccl" else uid
+            dist.broadcast(carrier, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            uid = carrier.cpu()
+        h = C.c_void_p()
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check(self._lib.mdd_comm_create(C.c_void_p(uid.data_ptr()), self.rank, self.world, index, C.byref(h)))
+        self.h = h
+
+    def all_reduce_mean_(self, flat):
+        import ctypes as C
+        if flat.dtype != torch.float32 or not flat.is_contiguous() or flat.device != self.device:
+            raise RuntimeError("LibraryCollective: a contiguous fp32 tensor on %s is required" % self.device)
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        self._lib_mod.check(self._lib.mdd_allreduce_syn_grads(self.h, C.c_void_p(flat.data_ptr()), flat.numel(), 1, st))
+        return flat
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.mdd_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class DeferredStop:

@@ -96,3 +96,47 @@ def test_two_ranks_on_one_gpu_with_the_engine_in_the_loop(mode, report, tmp_path
         assert torch.isfinite(a[k]).all() and torch.equal(a[k], b[k]), k       # identical update on every rank
     report("mode %s, 2 ranks x engine on one GPU (gloo): identical synthetic set on both ranks, |img| %.4f"
            % (mode, a["img"].norm().item()))
+
+
+@pytest.mark.gpu
+def test_library_rccl_allreduce_single_rank_and_through_the_stop_logic(report):
+    """`mdd_allreduce_syn_grads` (include/mdd_hip.h): the library binds RCCL at run time, creates its
+    own communicator and all-reduces in the caller's stream.  This pool has one GPU per box and RCCL refuses two
+    ranks on one device, so the collective itself is exercised at world size 1 (sum over one rank = identity,
+    the mean divides by 1): what is checked is the binding (dlopen of the process's librccl, the symbols, the
+    unique-id hand-over, communicator init on the right device, stream ordering, teardown) and that the
+    mode-A stop logic runs unchanged on top of it."""
+    import ctypes as C
+    from multimodal_dataset_distillation_amd import _lib, parallel as par
+    dev = torch.device("cuda", 0)
+    coll = par.LibraryCollective(dev)
+    assert coll.world == 1 and _lib.load().mdd_comm_world(coll.h) == 1
+    g = torch.Generator(device=dev).manual_seed(5)
+    image_syn, text_syn = torch.randn(4, 3, 16, 16, device=dev, generator=g), torch.randn(4, 8, device=dev, generator=g)
+    flat, views = par.fused_grad_buffer(image_syn, text_syn)
+    flat[:-1].copy_(torch.randn(flat.numel() - 1, device=dev, generator=g))
+    want = flat.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                 # the collective runs in the CALLER's current stream
+        flat.mul_(2.0)
+        coll.all_reduce_mean_(flat)
+        flat.mul_(0.5)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(flat, want)
+    # the NaN stop rides through the same buffer
+    stop = par.DeferredStop(dev)
+    losses = torch.tensor([float("nan"), 1.0, 1.0], device=dev)
+    stop.update(flat, views, losses, reduce=True, group=coll, iteration=0)
+    assert stop.last()[0] is True and float(views["nan_flag"]) == 1.0
+    # argument errors come back through mdd_last_error, not as a crash
+    with pytest.raises(RuntimeError, match="contiguous fp32"):
+        coll.all_reduce_mean_(flat.double())
+    h = C.c_void_p()
+    uid = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
+    rc = _lib.load().mdd_comm_create(C.c_void_p(uid.data_ptr()), 3, 2, 0, C.byref(h))   # rank >= world
+    assert rc != 0 and b"invalid argument" in _lib.load().mdd_last_error()
+    coll.close()
+    coll.close()                                   # idempotent
+    report("library RCCL all-reduce: world 1 identity ok, stop logic ok")

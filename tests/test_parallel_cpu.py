@@ -175,3 +175,11 @@ def test_mode_b_collective_driver_equals_the_lockstep_driver():
         for k in ("X", "g", "X2", "h"):
             assert torch.equal(out[r][k], want[r][k]), (r, k)
     assert torch.equal(out[0]["X"], out[1]["X"]) and torch.equal(out[0]["h"], torch.full((3,), 3.0))
+
+
+def test_library_collective_has_no_cpu_path():
+    """The library-issued all-reduce is RCCL only: asking for it on a CPU device fails loudly."""
+    import pytest
+    from multimodal_dataset_distillation_amd import parallel as par
+    with pytest.raises(RuntimeError, match="needs a GPU"):
+        par.LibraryCollective("cpu")
