@@ -4,6 +4,10 @@
 // All tensors are [n, h*w, c] with c contiguous; every access is a 16-byte chunk per lane.
 #include "kernels.h"
 
+#ifndef MDD_EW_TILED
+#define MDD_EW_TILED 1   // per-image tiled SE apply / gradient kernels (0: the flat grid-stride versions)
+#endif
+
 namespace {
 
 template <class AT> DEVI void ld_chunk(const AT* p, int64_t chunk_idx, float* f) {
@@ -191,62 +195,63 @@ __global__ __launch_bounds__(128, 4) void k_stem_dgrad_image(float* __restrict__
 }
 
 // ------------------------------------------------------------------ AvgPool2d(2, stride, ceil_mode, count_include_pad=False)
+// One block per (image, output row); threads walk the row's (ox, chunk column) pairs -- 32-bit index
+// arithmetic only (a flat 64-bit index costs three 64-bit divisions per 16-byte chunk).
 template <class AT>
 __global__ void k_avgpool2(AT* __restrict__ out, const AT* __restrict__ in, int n, int h, int w,
                            int c, int stride, int ho, int wo) {
   constexpr int CE = Chunk<AT>::N;
-  int cch = c / CE;
-  int64_t total = (int64_t)n * ho * wo * cch;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    int cc = (int)(i % cch);
-    int64_t p = i / cch;
-    int ox = (int)(p % wo);
-    int oy = (int)((p / wo) % ho);
-    int ni = (int)(p / ((int64_t)wo * ho));
+  const int cch = c / CE;
+  const int ni = blockIdx.x / ho, oy = blockIdx.x - ni * ho;
+  const int iy = oy * stride;
+  const int ny = (iy + 1 < h) ? 2 : 1;
+  const int64_t in_row = ((int64_t)ni * h + iy) * w * cch;
+  const int64_t out_row = ((int64_t)ni * ho + oy) * wo * cch;
+  const int items = wo * cch;
+  for (int j = threadIdx.x; j < items; j += blockDim.x) {
+    const int ox = j / cch, cc = j - ox * cch;
+    const int ix = ox * stride;
+    const int nx = (ix + 1 < w) ? 2 : 1;
+    // the four window taps are loaded unconditionally (clamped to the last valid row / column, weight 0 when
+    // outside) so that all four loads are in flight together
+    const int64_t b00 = in_row + (int64_t)ix * cch + cc;
+    const int64_t dxo = (nx == 2) ? cch : 0, dyo = (ny == 2) ? (int64_t)w * cch : 0;
+    float f00[CE], f01[CE], f10[CE], f11[CE];
+    ld_chunk<AT>(in, b00, f00);
+    ld_chunk<AT>(in, b00 + dxo, f01);
+    ld_chunk<AT>(in, b00 + dyo, f10);
+    ld_chunk<AT>(in, b00 + dyo + dxo, f11);
+    const float wx = nx == 2 ? 1.f : 0.f, wy = ny == 2 ? 1.f : 0.f;
+    const float r = 1.f / (ny * nx);
     float acc[CE];
 #pragma unroll
-    for (int e = 0; e < CE; ++e) acc[e] = 0.f;
-    int cnt = 0;
-    for (int dy = 0; dy < 2; ++dy)
-      for (int dx = 0; dx < 2; ++dx) {
-        int iy = oy * stride + dy, ix = ox * stride + dx;
-        if (iy < h && ix < w) {
-          float f[CE];
-          ld_chunk<AT>(in, (((int64_t)ni * h + iy) * w + ix) * cch + cc, f);
-#pragma unroll
-          for (int e = 0; e < CE; ++e) acc[e] += f[e];
-          ++cnt;
-        }
-      }
-    float r = 1.f / cnt;
-#pragma unroll
-    for (int e = 0; e < CE; ++e) acc[e] *= r;
-    st_chunk<AT>(out, i, acc);
+    for (int e = 0; e < CE; ++e) acc[e] = (f00[e] + wx * f01[e] + wy * f10[e] + wx * wy * f11[e]) * r;
+    st_chunk<AT>(out, out_row + j, acc);
   }
 }
-// stride == 2 only (non-overlapping windows): din[iy,ix] = dout[iy/2, ix/2] / count
+// stride == 2 only (non-overlapping windows): din[iy,ix] = dout[iy/2, ix/2] / count.  One block per
+// (image, input row).
 template <class AT>
 __global__ void k_avgpool2_bwd(AT* __restrict__ din, const AT* __restrict__ dout, int n, int h,
                                int w, int c, int ho, int wo) {
   constexpr int CE = Chunk<AT>::N;
-  int cch = c / CE;
-  int64_t total = (int64_t)n * h * w * cch;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    int cc = (int)(i % cch);
-    int64_t p = i / cch;
-    int ix = (int)(p % w);
-    int iy = (int)((p / w) % h);
-    int ni = (int)(p / ((int64_t)w * h));
-    int oy = iy >> 1, ox = ix >> 1;
-    int cy = (oy * 2 + 1 < h) ? 2 : 1, cx = (ox * 2 + 1 < w) ? 2 : 1;
+  const int cch = c / CE;
+  const int ni = blockIdx.x / h, iy = blockIdx.x - ni * h;
+  const int oy = iy >> 1;
+  const int cy = (oy * 2 + 1 < h) ? 2 : 1;
+  const int64_t in_row = ((int64_t)ni * h + iy) * w * cch;
+  const int64_t out_row = ((int64_t)ni * ho + oy) * wo * cch;
+  const int items = w * cch;
+  for (int j = threadIdx.x; j < items; j += blockDim.x) {
+    const int ix = j / cch, cc = j - ix * cch;
+    const int ox = ix >> 1;
+    const int cx = (ox * 2 + 1 < w) ? 2 : 1;
     float f[CE];
-    ld_chunk<AT>(dout, (((int64_t)ni * ho + oy) * wo + ox) * cch + cc, f);
-    float r = 1.f / (cy * cx);
+    ld_chunk<AT>(dout, out_row + (int64_t)ox * cch + cc, f);
+    const float r = 1.f / (cy * cx);
 #pragma unroll
     for (int e = 0; e < CE; ++e) f[e] *= r;
-    st_chunk<AT>(din, i, f);
+    st_chunk<AT>(din, in_row + j, f);
   }
 }
 
@@ -398,6 +403,110 @@ __global__ void k_final_pool_bwd(AT* __restrict__ cfbar, AT* __restrict__ cfbar_
   }
 }
 
+
+// ------------------------------------------------------------------ tiled variants of the per-(image, channel) broadcasts
+// block = 32 chunk columns x 8 row lanes of ONE image (grid: image x column tile x row split).  The flat
+// grid-stride versions above pay two 64-bit integer divisions per 16-byte chunk (image and column of a flat
+// index) and re-load the [n, c] operands (gate, pooled gradient) for every chunk; here they are loaded once per
+// thread, and the row loop is 32-bit address arithmetic only.  Used whenever c is a multiple of 32 chunks.
+struct RowTile {
+  int ni, cc, p0, p1;      // image, chunk column, first row of this thread, end row; rows advance by 8
+  size_t base;             // chunk index of (ni, row 0, cc)
+};
+template <int CE> DEVI RowTile row_tile(int hw, int c, int rows_per_block) {
+  RowTile t;
+  const int cch = c / CE;
+  t.ni = blockIdx.x;
+  t.cc = blockIdx.y * 32 + (threadIdx.x & 31);
+  const int r0 = blockIdx.z * rows_per_block;
+  t.p0 = r0 + (threadIdx.x >> 5);
+  t.p1 = min(hw, r0 + rows_per_block);
+  t.base = (size_t)t.ni * hw * cch + t.cc;
+  return t;
+}
+template <class S, class AT>
+__global__ __launch_bounds__(256) void k_se_apply_tiled(
+    const AT* __restrict__ c3, const AT* __restrict__ c3_t, const float* __restrict__ gate,
+    const float* __restrict__ gate_t, const AT* __restrict__ sc, const AT* __restrict__ sc_t,
+    AT* __restrict__ xo, AT* __restrict__ xo_t, AT* __restrict__ ao, AT* __restrict__ ao_t, float ga,
+    float beta, int hw, int c, int rows_per_block) {
+  constexpr int CE = Chunk<AT>::N;
+  const int cch = c / CE;
+  const RowTile t = row_tile<CE>(hw, c, rows_per_block);
+  S g[CE];
+#pragma unroll
+  for (int e = 0; e < CE; ++e) g[e] = ldS<S>(gate, gate_t, (size_t)t.ni * c + t.cc * CE + e) * ga;
+  const bool act = ao || ao_t;
+  for (int p = t.p0; p < t.p1; p += 8) {
+    const size_t i = t.base + (size_t)p * cch;
+    S x[CE], s_[CE], xo_[CE], ao_[CE];
+    ld_chunkS<S, AT>(c3, c3_t, i, x);
+    ld_chunkS<S, AT>(sc, sc_t, i, s_);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+      xo_[e] = x[e] * g[e] + s_[e];
+      ao_[e] = silu_(xo_[e]) * beta;
+    }
+    st_chunkS<S, AT>(xo, xo_t, i, xo_);
+    if (act) st_chunkS<S, AT>(ao, ao_t, i, ao_);
+  }
+}
+template <class S, class AT>
+__global__ __launch_bounds__(256) void k_se_apply_bwd_tiled(
+    AT* __restrict__ c3bar, AT* __restrict__ c3bar_t, const AT* __restrict__ xbar,
+    const AT* __restrict__ xbar_t, const float* __restrict__ gate, const float* __restrict__ gate_t,
+    const float* __restrict__ pbar, const float* __restrict__ pbar_t, float ga, int hw, int c,
+    int rows_per_block) {
+  constexpr int CE = Chunk<AT>::N;
+  const int cch = c / CE;
+  const RowTile t = row_tile<CE>(hw, c, rows_per_block);
+  const float rhw = 1.f / hw;
+  S g[CE], pb[CE];
+#pragma unroll
+  for (int e = 0; e < CE; ++e) {
+    const size_t gi = (size_t)t.ni * c + t.cc * CE + e;
+    g[e] = ldS<S>(gate, gate_t, gi) * ga;
+    pb[e] = ldS<S>(pbar, pbar_t, gi) * rhw;
+  }
+  for (int p = t.p0; p < t.p1; p += 8) {
+    const size_t i = t.base + (size_t)p * cch;
+    S x[CE], o[CE];
+    ld_chunkS<S, AT>(xbar, xbar_t, i, x);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) o[e] = x[e] * g[e] + pb[e];
+    st_chunkS<S, AT>(c3bar, c3bar_t, i, o);
+  }
+}
+template <class S, class AT>
+__global__ __launch_bounds__(256) void k_final_pool_bwd_tiled(
+    AT* __restrict__ cfbar, AT* __restrict__ cfbar_t, const float* __restrict__ ybar,
+    const float* __restrict__ ybar_t, const AT* __restrict__ cf, const AT* __restrict__ cf_t, int hw,
+    int c, int rows_per_block) {
+  constexpr int CE = Chunk<AT>::N;
+  const int cch = c / CE;
+  const RowTile t = row_tile<CE>(hw, c, rows_per_block);
+  const float rhw = 1.f / hw;
+  S yb[CE];
+#pragma unroll
+  for (int e = 0; e < CE; ++e) yb[e] = ldS<S>(ybar, ybar_t, (size_t)t.ni * c + t.cc * CE + e) * rhw;
+  for (int p = t.p0; p < t.p1; p += 8) {
+    const size_t i = t.base + (size_t)p * cch;
+    S x[CE], o[CE];
+    ld_chunkS<S, AT>(cf, cf_t, i, x);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) o[e] = yb[e] * dsilu_(x[e]);
+    st_chunkS<S, AT>(cfbar, cfbar_t, i, o);
+  }
+}
+// rows per block: about 64 (eight per thread), the row range split evenly and rounded up to the 8 row lanes
+inline bool tiled_ok(int c, int ce) { return (c % ce) == 0 && ((c / ce) % 32) == 0; }
+inline dim3 tiled_grid(int n, int hw, int c, int ce, int* rows_per_block) {
+  const int splits = (hw + 63) / 64;
+  const int rpb = (((hw + splits - 1) / splits) + 7) & ~7;
+  *rows_per_block = rpb;
+  return dim3((unsigned)n, (unsigned)(c / ce / 32), (unsigned)((hw + rpb - 1) / rpb));
+}
+
 }  // namespace
 
 // ====================================================================== launchers
@@ -428,15 +537,13 @@ template <class AT>
 void launch_avgpool2(AT* out, const AT* in, int n, int h, int w, int c, int stride,
                      hipStream_t st) {
   int ho = (h + stride - 1) / stride, wo = (w + stride - 1) / stride;
-  int64_t total = (int64_t)n * ho * wo * (c / Chunk<AT>::N);
-  k_avgpool2<AT><<<egrid(total), 256, 0, st>>>(out, in, n, h, w, c, stride, ho, wo);
+  k_avgpool2<AT><<<n * ho, 256, 0, st>>>(out, in, n, h, w, c, stride, ho, wo);
 }
 template <class AT>
 void launch_avgpool2_bwd(AT* din, const AT* dout, int n, int h, int w, int c, int stride,
                          hipStream_t st) {
   int ho = (h + stride - 1) / stride, wo = (w + stride - 1) / stride;
-  int64_t total = (int64_t)n * h * w * (c / Chunk<AT>::N);
-  k_avgpool2_bwd<AT><<<egrid(total), 256, 0, st>>>(din, dout, n, h, w, c, ho, wo);
+  k_avgpool2_bwd<AT><<<n * h, 256, 0, st>>>(din, dout, n, h, w, c, ho, wo);
 }
 template <class AT>
 void launch_pool_mean(float* p, const AT* x, int n, int hw, int c, hipStream_t st) {
@@ -449,6 +556,17 @@ void launch_se_apply(const AT* c3, const AT* c3_t, const float* gate, const floa
                      const AT* sc, const AT* sc_t, AT* xo, AT* xo_t, AT* ao, AT* ao_t, float ga,
                      float beta, int n, int hw, int c, hipStream_t st) {
   int64_t total = (int64_t)n * hw * (c / Chunk<AT>::N);
+  if (MDD_EW_TILED && tiled_ok(c, Chunk<AT>::N)) {
+    int rpb;
+    const dim3 grid = tiled_grid(n, hw, c, Chunk<AT>::N, &rpb);
+    if (c3_t)
+      k_se_apply_tiled<Dual, AT><<<grid, 256, 0, st>>>(c3, c3_t, gate, gate_t, sc, sc_t, xo, xo_t, ao, ao_t, ga,
+                                                       beta, hw, c, rpb);
+    else
+      k_se_apply_tiled<float, AT><<<grid, 256, 0, st>>>(c3, nullptr, gate, nullptr, sc, nullptr, xo, nullptr, ao,
+                                                        nullptr, ga, beta, hw, c, rpb);
+    return;
+  }
   if (c3_t)
     k_se_apply<Dual, AT><<<egrid(total), 256, 0, st>>>(c3, c3_t, gate, gate_t, sc, sc_t, xo, xo_t,
                                                        ao, ao_t, ga, beta, total, hw, c);
@@ -474,6 +592,17 @@ void launch_se_apply_bwd(AT* c3bar, AT* c3bar_t, const AT* xbar, const AT* xbar_
                          const float* gate, const float* gate_t, const float* pbar,
                          const float* pbar_t, float ga, int n, int hw, int c, hipStream_t st) {
   int64_t total = (int64_t)n * hw * (c / Chunk<AT>::N);
+  if (MDD_EW_TILED && tiled_ok(c, Chunk<AT>::N)) {
+    int rpb;
+    const dim3 grid = tiled_grid(n, hw, c, Chunk<AT>::N, &rpb);
+    if (xbar_t)
+      k_se_apply_bwd_tiled<Dual, AT><<<grid, 256, 0, st>>>(c3bar, c3bar_t, xbar, xbar_t, gate, gate_t, pbar, pbar_t,
+                                                           ga, hw, c, rpb);
+    else
+      k_se_apply_bwd_tiled<float, AT><<<grid, 256, 0, st>>>(c3bar, nullptr, xbar, nullptr, gate, nullptr, pbar,
+                                                            nullptr, ga, hw, c, rpb);
+    return;
+  }
   if (xbar_t)
     k_se_apply_bwd<Dual, AT><<<egrid(total), 256, 0, st>>>(c3bar, c3bar_t, xbar, xbar_t, gate,
                                                            gate_t, pbar, pbar_t, ga, total, hw, c);
@@ -497,6 +626,15 @@ template <class AT>
 void launch_final_pool_bwd(AT* cfbar, AT* cfbar_t, const float* ybar, const float* ybar_t,
                            const AT* cf, const AT* cf_t, int n, int hw, int c, hipStream_t st) {
   int64_t total = (int64_t)n * hw * (c / Chunk<AT>::N);
+  if (MDD_EW_TILED && tiled_ok(c, Chunk<AT>::N)) {
+    int rpb;
+    const dim3 grid = tiled_grid(n, hw, c, Chunk<AT>::N, &rpb);
+    if (cf_t)
+      k_final_pool_bwd_tiled<Dual, AT><<<grid, 256, 0, st>>>(cfbar, cfbar_t, ybar, ybar_t, cf, cf_t, hw, c, rpb);
+    else
+      k_final_pool_bwd_tiled<float, AT><<<grid, 256, 0, st>>>(cfbar, nullptr, ybar, nullptr, cf, nullptr, hw, c, rpb);
+    return;
+  }
   if (cf_t)
     k_final_pool_bwd<Dual, AT><<<egrid(total), 256, 0, st>>>(cfbar, cfbar_t, ybar, ybar_t, cf,
                                                              cf_t, total, hw, c);
