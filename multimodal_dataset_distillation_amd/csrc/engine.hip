@@ -37,6 +37,9 @@ int mdd_set_error_msg(int code, const char* msg) {
   g_err = msg;
   return code;
 }
+#ifndef MDD_GRAPH
+#define MDD_GRAPH 0      // 1: mdd_unrolled_match replays a captured hipGraph (experiment build)
+#endif
 #define CHECK_ARG(cond, msg) \
   do { if (!(cond)) return mdd_set_error_msg(2, "mdd: invalid argument: " msg); } while (0)
 #define POST_LAUNCH(what) HIP_CHECK_RET(hipGetLastError())
@@ -477,6 +480,9 @@ struct Eng : mdd_engine {
   hipStream_t side = nullptr;
   bool use_side = true;
   ~Eng() override {   // streams / events created at bind(); the workspace belongs to the caller
+#if MDD_GRAPH
+    if (gexec) (void)hipGraphExecDestroy(gexec);
+#endif
     if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
     if (tside) { (void)hipStreamSynchronize(tside); (void)hipStreamDestroy(tside); }
     for (auto e : evs) (void)hipEventDestroy(e);
@@ -934,7 +940,41 @@ struct Eng : mdd_engine {
   }
 
   // ------------------------------------------------------------------ whole outer iteration
+#if MDD_GRAPH
+  // Experiment (profiles/r02_experiments.md): the whole outer iteration captured into ONE hipGraph (three
+  // streams, their event edges included) and replayed while the call's arguments stay the same.
+  hipGraphExec_t gexec = nullptr;
+  std::vector<uint64_t> gkey;
   int unrolled_match(const mdd_iter_args* a, hipStream_t st) override {
+    if (!st || prof_on) return unrolled_match_enqueue(a, st);     // the legacy default stream cannot be captured
+    DevGuard guard(device_id);
+    std::vector<uint64_t> key;
+    const void* ptrs[] = {a->image_syn, a->text_syn, a->lr_img, a->lr_txt, a->theta0_img, a->theta0_txt,
+                          a->target_img, a->target_txt, a->perms, a->drop_masks, a->grad_image_syn,
+                          a->grad_text_syn, a->grad_lr, a->losses, (const void*)st};
+    for (const void* q : ptrs) key.push_back((uint64_t)(uintptr_t)q);
+    key.push_back((uint64_t)a->syn_steps); key.push_back((uint64_t)a->use_lr_as_scale);
+    uint32_t lsb; memcpy(&lsb, &a->logit_scale_const, 4); key.push_back(lsb);
+    if (!gexec || key != gkey) {
+      if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
+      HIP_CHECK_RET(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+      int rc = unrolled_match_enqueue(a, st);
+      hipGraph_t g = nullptr;
+      hipError_t e = hipStreamEndCapture(st, &g);
+      if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+      HIP_CHECK_RET(e);
+      e = hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      HIP_CHECK_RET(e);
+      gkey = key;
+    }
+    HIP_CHECK_RET(hipGraphLaunch(gexec, st));
+    return 0;
+  }
+  int unrolled_match_enqueue(const mdd_iter_args* a, hipStream_t st) {
+#else
+  int unrolled_match(const mdd_iter_args* a, hipStream_t st) override {
+#endif
     CHECK_ARG(base, "workspace not bound");
     DevGuard guard(device_id);
     CHECK_ARG(a->syn_steps >= 1 && a->syn_steps <= K, "syn_steps exceeds the engine's slots");

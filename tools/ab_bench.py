@@ -15,8 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def one(lib_path, dtype, steps, workload):
+def one(lib_path, dtype, steps, workload, own_stream=False):
     import torch
+    if own_stream:
+        torch.cuda.set_stream(torch.cuda.Stream())
     from multimodal_dataset_distillation_amd import _lib
     _lib.LIB_PATH = os.path.abspath(lib_path)
     os.environ.pop("MDD_HIP_LIB", None)
@@ -66,14 +68,15 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--workload", default="c2")
+    ap.add_argument("--stream", action="store_true", help="run on a non-default HIP stream (graph-capture builds)")
     ap.add_argument("libs", nargs="*")
     a = ap.parse_args()
     if a.one:
-        one(a.one, a.dtype, a.steps, a.workload)
+        one(a.one, a.dtype, a.steps, a.workload, a.stream)
         return
     for lib in a.libs:
         rc = subprocess.call([sys.executable, os.path.abspath(__file__), "--one", lib, "--dtype", a.dtype,
-                              "--steps", str(a.steps), "--workload", a.workload])
+                              "--steps", str(a.steps), "--workload", a.workload] + (["--stream"] if a.stream else []))
         if rc:
             print("FAILED", lib, rc, flush=True)
 
