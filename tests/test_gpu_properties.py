@@ -11,16 +11,17 @@ that fits), but the calculus the four passes implement has identities that hold 
 J = d y / d theta of the image encoder (reference networks.py:678-682 under ReparamModule, distill.py:524) and of the
 text projection (networks.py:639-646, distill.py:537); these are the operators `grand_loss.backward()` applies at
 distill.py:606.  A kernel that drops a term, reads a stale stash or mis-indexes a tile breaks an identity by O(1);
-rounding moves it by the mode's per-contraction error.  Bars = 4-10x the values measured on MI355X (the report line)."""
+rounding moves it by far less (the directions below make both sides of each identity sums of like-signed terms, so
+per-contraction rounding averages out).  Bars = 4-100x the values measured on MI355X (the report line)."""
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
 #            duality  symmetry  linearity
-# measured (MI355X, round 2): f32 6.8e-7 / 1.6e-6 / 2.2e-6; bf16x2 1.3e-5 / 3.3e-4 / 9.2e-6; bf16 7.1e-3 / 7.7e-3 / 6.2e-3
-BARS = {"f32": (1e-5, 2e-5, 2e-5), "bf16x2": (1e-4, 1.5e-3, 1e-4), "bf16": (3e-2, 3e-2, 3e-2)}
-
+# measured (MI355X, round 2): f32 1.1e-8 / 1.1e-8 / 9.3e-7; bf16x2 7.0e-8 / 9.6e-7 / 2.3e-6;
+# bf16 nfnet_l0 N=100 1.5e-5 / 5.1e-5 / 1.6e-3, nfnet_l1 N=500 3.2e-6 / 4.8e-5 / 2.6e-3
+BARS = {"f32": (1e-6, 1e-6, 1e-5), "bf16x2": (5e-6, 1e-5, 2e-5), "bf16": (2e-4, 5e-4, 1e-2)}
 
 def _dot(a, b):
     return float((a.double().flatten() @ b.double().flatten()).item())
@@ -30,27 +31,33 @@ def _rel(a, b):
     return abs(a - b) / max(abs(a), abs(b), 1e-30)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16x2", "bf16"])
-def test_image_encoder_identities_at_full_size(dtype, report):
+@pytest.mark.parametrize("variant,n,dtype", [
+    ("nfnet_l0", 100, "f32"), ("nfnet_l0", 100, "bf16x2"), ("nfnet_l0", 100, "bf16"),
+    # BASELINE configs[3]'s per-GPU shape: NFNet-l1, 500 pairs (1.57 M rows at 56^2, 150 GiB of activations for
+    # one step + the tangent set).  Only bf16 fits one GPU, and no other test can check numbers at this size.
+    ("nfnet_l1", 500, "bf16"),
+])
+def test_image_encoder_identities_at_full_size(variant, n, dtype, report):
     from multimodal_dataset_distillation_amd.engine import UnrollEngine
     from multimodal_dataset_distillation_amd.networks import synthetic_expert_params
     dev = torch.device("cuda", 0)
-    n, size, d_txt = 100, 224, 768
-    eng = UnrollEngine("nfnet_l0", batch=n, num_queries=n, image_size=size, d_txt=d_txt, syn_steps=1, dtype=dtype,
+    size, d_txt = 224, 768
+    eng = UnrollEngine(variant, batch=n, num_queries=n, image_size=size, d_txt=d_txt, syn_steps=1, dtype=dtype,
                        device=dev)
     g = torch.Generator(device=dev).manual_seed(11)
     theta, theta_t = synthetic_expert_params(eng, seed=3, device=dev)
     x = torch.randn(n, 3, size, size, device=dev, generator=g)
     w = torch.randn(n, eng.feature_dim, device=dev, generator=g) / eng.feature_dim ** 0.5
-    # directions with the parameters' own per-element scale
-    u = theta * torch.randn(theta.shape, device=dev, generator=g) + 1e-3 * torch.randn(theta.shape, device=dev, generator=g)
-    v = theta * torch.randn(theta.shape, device=dev, generator=g) + 1e-3 * torch.randn(theta.shape, device=dev, generator=g)
     zeros = torch.zeros(n, eng.feature_dim, device=dev)
-
+    # Directions are chosen so that neither side of an identity is a sum that cancels (with random u, v the inner
+    # products are O(10) against |w||Ju| ~ 1e5 and their RELATIVE error measures luck, not kernels):
+    # u along J^T w makes <J^T w, u> = c |J^T w|^2, v along H_w u makes <v, H_w u> = c' |H_w u|^2.
     y = eng.img_forward(0, theta, x)
     gth = eng.img_backward(0, theta, w, stash=True)                       # J^T w, backward signals stashed
+    u = gth * (0.05 * float(theta.norm()) / float(gth.norm()))
     ju = eng.img_tangent_forward(0, theta, u)
     hu = eng.img_tangent_backward(0, theta, u, zeros)                     # H_w u
+    v = hu * (0.05 * float(theta.norm()) / float(hu.norm()))
     jv = eng.img_tangent_forward(0, theta, v)
     hv = eng.img_tangent_backward(0, theta, v, zeros)
     u3 = 3.0 * u
@@ -58,15 +65,17 @@ def test_image_encoder_identities_at_full_size(dtype, report):
     hu3 = eng.img_tangent_backward(0, theta, u3, zeros)
     torch.cuda.synchronize()
     assert all(bool(torch.isfinite(t).all()) for t in (y, gth, ju, hu, hv, hu3))
-    dual = max(_rel(_dot(w, ju), _dot(gth, u)), _rel(_dot(w, jv), _dot(gth, v)))
+    dual = _rel(_dot(w, ju), _dot(gth, u))
     sym = _rel(_dot(v, hu), _dot(u, hv))
     lin = float((hu3 - 3.0 * hu).norm() / (3.0 * hu).norm())
-    report(f"identities, image encoder N={n} @{size} {dtype}: duality {dual:.2e} symmetry {sym:.2e} "
-           f"linearity {lin:.2e} (|Ju| {float(ju.norm()):.3e} |Hu| {float(hu.norm()):.3e} <v,Hu> {_dot(v, hu):.3e})")
+    report(f"identities, image encoder {variant} N={n} @{size} {dtype}: duality {dual:.2e} symmetry {sym:.2e} "
+           f"linearity {lin:.2e} (<w,Ju> {_dot(w, ju):.4e} <g,u> {_dot(gth, u):.4e} <v,Hu> {_dot(v, hu):.4e} <u,Hv> {_dot(u, hv):.4e})")
     assert float(ju.norm()) > 0 and float(hu.norm()) > 0
     bd, bs, bl = BARS[dtype]
     assert dual < bd and sym < bs and lin < bl, (dual, sym, lin)
     eng.close()
+    del eng, y, gth, ju, hu, jv, hv, hu3
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -84,18 +93,18 @@ def test_text_projection_identities_at_full_size(dtype, report):
     x = torch.randn(n, d_txt, device=dev, generator=g) * 0.5
     mask = (torch.rand(n, eng.feature_dim, device=dev, generator=g) >= 0.1).float() / 0.9
     w = torch.randn(n, eng.feature_dim, device=dev, generator=g) / eng.feature_dim ** 0.5
-    u = 0.05 * torch.randn(theta.shape, device=dev, generator=g)
-    v = 0.05 * torch.randn(theta.shape, device=dev, generator=g)
     zeros = torch.zeros(n, eng.feature_dim, device=dev)
     eng.txt_forward(0, theta, x, None, mask)
     gth = eng.txt_backward(0, theta, w, stash=True)
+    u = gth * (0.05 * float(theta.norm()) / float(gth.norm()))
     ju = eng.txt_tangent_forward(0, theta, u)
     hu = eng.txt_tangent_backward(0, theta, u, zeros)
-    jv = eng.txt_tangent_forward(0, theta, v)
+    v = hu * (0.05 * float(theta.norm()) / float(hu.norm()))
+    eng.txt_tangent_forward(0, theta, v)
     hv = eng.txt_tangent_backward(0, theta, v, zeros)
     torch.cuda.synchronize()
-    dual = max(_rel(_dot(w, ju), _dot(gth, u)), _rel(_dot(w, jv), _dot(gth, v)))
+    dual = _rel(_dot(w, ju), _dot(gth, u))
     sym = _rel(_dot(v, hu), _dot(u, hv))
     report(f"identities, text projection N={n} {dtype}: duality {dual:.2e} symmetry {sym:.2e}")
-    assert dual < 2e-5 and sym < 2e-5, (dual, sym)        # the head computes in fp32 in every mode (measured <= 1.9e-6)
+    assert dual < 1e-6 and sym < 1e-6, (dual, sym)        # the head computes in fp32 in every mode (measured <= 1.5e-8)
     eng.close()
