@@ -37,6 +37,9 @@ int mdd_set_error_msg(int code, const char* msg) {
   g_err = msg;
   return code;
 }
+#ifndef MDD_SIDE_PRIORITY
+#define MDD_SIDE_PRIORITY 0   // bit 0: weight-gradient stream at least priority; bit 1: text stream (experiment builds)
+#endif
 #ifndef MDD_GRAPH
 #define MDD_GRAPH 0      // 1: mdd_unrolled_match replays a captured hipGraph (experiment build)
 #endif
@@ -455,8 +458,16 @@ struct Eng : mdd_engine {
       const char* env = getenv("MDD_SIDE_STREAM");
       use_side = !(env && env[0] == '0');
 #endif
+#if MDD_SIDE_PRIORITY
+      // experiment: the weight-gradient (1) / text (2) streams below the caller's stream in queue priority
+      int prio_lo = 0, prio_hi = 0;
+      HIP_CHECK_RET(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));   // lo = least priority (largest number)
+      if (use_side) HIP_CHECK_RET(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, (MDD_SIDE_PRIORITY & 1) ? prio_lo : 0));
+      if (use_side) HIP_CHECK_RET(hipStreamCreateWithPriority(&tside, hipStreamNonBlocking, (MDD_SIDE_PRIORITY & 2) ? prio_lo : 0));
+#else
       if (use_side) HIP_CHECK_RET(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
       if (use_side) HIP_CHECK_RET(hipStreamCreateWithFlags(&tside, hipStreamNonBlocking));
+#endif
     }
     return 0;
   }

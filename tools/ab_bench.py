@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 def one(lib_path, dtype, steps, workload, own_stream=False):
     import torch
     if own_stream:
-        torch.cuda.set_stream(torch.cuda.Stream())
+        torch.cuda.set_stream(torch.cuda.Stream(priority=-1 if own_stream == "high" else 0))
     from multimodal_dataset_distillation_amd import _lib
     _lib.LIB_PATH = os.path.abspath(lib_path)
     os.environ.pop("MDD_HIP_LIB", None)
@@ -68,7 +68,8 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--workload", default="c2")
-    ap.add_argument("--stream", action="store_true", help="run on a non-default HIP stream (graph-capture builds)")
+    ap.add_argument("--stream", nargs="?", const="normal", default=None, choices=["normal", "high"],
+                    help="run on a non-default HIP stream (graph-capture builds); 'high' = a high-priority stream")
     ap.add_argument("libs", nargs="*")
     a = ap.parse_args()
     if a.one:
@@ -76,7 +77,7 @@ def main():
         return
     for lib in a.libs:
         rc = subprocess.call([sys.executable, os.path.abspath(__file__), "--one", lib, "--dtype", a.dtype,
-                              "--steps", str(a.steps), "--workload", a.workload] + (["--stream"] if a.stream else []))
+                              "--steps", str(a.steps), "--workload", a.workload] + (["--stream", a.stream] if a.stream else []))
         if rc:
             print("FAILED", lib, rc, flush=True)
 
