@@ -65,9 +65,9 @@ typedef struct mdd_config {
 
 const char* mdd_last_error(void);
 /* ABI version of this header: 2 = round 2 (mdd_config.keep_steps, MDD_DTYPE_BF16X2 / _F32_BF16OPS,
- * profile kind 4); 3 = + mdd_comm_* / mdd_allreduce_syn_grads.  A binding built against another version
+ * profile kind 4); 3 = + mdd_comm_* / mdd_allreduce_syn_grads; 4 = + the ViT building-block ops.  A binding built against another version
  * must refuse to load. */
-#define MDD_ABI_VERSION 3
+#define MDD_ABI_VERSION 4
 int mdd_version(void);
 
 /* ---- engine lifetime and memory (the caller owns device memory: PyTorch caching allocator) */
@@ -230,6 +230,40 @@ int mdd_comm_create(const void* id, int rank, int world, int device_id, mdd_comm
 void mdd_comm_destroy(mdd_comm* c);
 int mdd_comm_world(const mdd_comm* c);
 int mdd_allreduce_syn_grads(mdd_comm* c, float* buf_dev, int64_t n, int average, void* stream);
+
+/* ---- ViT building blocks (BASELINE configs[4]: ViT-B/16 image encoder; csrc/vit.hip).
+ * The operators of timm 0.6.7's VisionTransformer block (what the reference reaches through timm / clip,
+ * networks.py:661,668) that the NFNet path does not have, each as forward, backward and -- when the `*_t` tangent
+ * pointers are non-NULL -- the tangent of either (the double backward of distill.py:606).  A tangent call reads the
+ * primal operands and writes ONLY the `*_t` outputs.  dtype: MDD_DTYPE_F32 or MDD_DTYPE_BF16 = the storage type of
+ * the activation tensors (`void*`); parameters, scores and probabilities are fp32.  Row-major, 16-byte aligned.
+ *   layernorm      y = (x - mean) * rstd * gamma + beta over rows of `dim`            (eps 1e-6 in ViT)
+ *   layernorm_bwd  dx, and dgamma / dbeta ACCUMULATED (+=, fp32 atomics) into the caller's zeroed/partial sums
+ *   gelu           a = GELU(c) (exact, erf);  gelu_bwd  cbar = abar * GELU'(c)
+ *   softmax        p = softmax(scale * s) over `cols` of each row (row stride ld); softmax_bwd  ds = scale*p*(dp - <p,dp>)
+ *   bgemm          C[b] = alpha * A[b] B[b] for b = (o < outer, q < inner), every operand addressed by element strides
+ *                  (transposes and the head slices of a fused qkv tensor need no copy).  bf16 dtype: a_is_f32 /
+ *                  c_is_f32 say which of A, C are fp32 tensors (scores, probabilities); B is always activation-typed. */
+typedef struct mdd_bgemm_desc {
+  int32_t m, n, k, outer, inner;
+  int64_t a_row, a_col, b_row, b_col, c_row, c_col;               /* A(i,kk) = A[i*a_row + kk*a_col], B(kk,j) = B[kk*b_row + j*b_col] */
+  int64_t a_outer, a_inner, b_outer, b_inner, c_outer, c_inner;   /* batch strides in elements */
+  float alpha;
+} mdd_bgemm_desc;
+int mdd_op_layernorm(int dtype, int rows, int dim, float eps, const void* x, const void* x_t, const float* gamma,
+                     const float* gamma_t, const float* beta, const float* beta_t, void* y, void* y_t, void* stream);
+int mdd_op_layernorm_bwd(int dtype, int rows, int dim, float eps, const void* x, const void* x_t, const void* dy,
+                         const void* dy_t, const float* gamma, const float* gamma_t, void* dx, void* dx_t,
+                         float* dgamma, float* dgamma_t, float* dbeta, float* dbeta_t, void* stream);
+int mdd_op_gelu(int dtype, int64_t n, const void* c, const void* c_t, void* a, void* a_t, void* stream);
+int mdd_op_gelu_bwd(int dtype, int64_t n, const void* c, const void* c_t, const void* abar, const void* abar_t,
+                    void* cbar, void* cbar_t, void* stream);
+int mdd_op_softmax(int64_t rows, int cols, int ld, float scale, const float* s, const float* s_t, float* p,
+                   float* p_t, void* stream);
+int mdd_op_softmax_bwd(int64_t rows, int cols, int ld, float scale, const float* p, const float* p_t,
+                       const float* dp, const float* dp_t, float* ds, float* ds_t, void* stream);
+int mdd_op_bgemm(int dtype, int a_is_f32, int c_is_f32, const mdd_bgemm_desc* d, const void* A, const void* A_t,
+                 const void* B, const void* B_t, void* C, void* C_t, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmdd_hip.so")
 
 DTYPE_F32, DTYPE_BF16, DTYPE_BF16X2, DTYPE_F32_BF16OPS = 0, 1, 2, 3
-ABI_VERSION = 3     # include/mdd_hip.h MDD_ABI_VERSION
+ABI_VERSION = 4     # include/mdd_hip.h MDD_ABI_VERSION
 
 
 class MddConfig(C.Structure):
@@ -74,7 +74,24 @@ SIGNATURES = {
     "mdd_comm_destroy": (None, [_P]),
     "mdd_comm_world": (_I, [_P]),
     "mdd_allreduce_syn_grads": (_I, [_P, _P, _L, _I, _P]),
+    "mdd_op_layernorm": (_I, [_I, _I, _I, _F] + [_P] * 9),
+    "mdd_op_layernorm_bwd": (_I, [_I, _I, _I, _F] + [_P] * 13),
+    "mdd_op_gelu": (_I, [_I, _L] + [_P] * 5),
+    "mdd_op_gelu_bwd": (_I, [_I, _L] + [_P] * 7),
+    "mdd_op_softmax": (_I, [_L, _I, _I, _F] + [_P] * 5),
+    "mdd_op_softmax_bwd": (_I, [_L, _I, _I, _F] + [_P] * 7),
+    "mdd_op_bgemm": (_I, [_I, _I, _I] + [_P] * 8),
 }
+
+
+class MddBgemmDesc(C.Structure):
+    _fields_ = [("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("outer", C.c_int32), ("inner", C.c_int32),
+                ("a_row", C.c_int64), ("a_col", C.c_int64), ("b_row", C.c_int64), ("b_col", C.c_int64),
+                ("c_row", C.c_int64), ("c_col", C.c_int64),
+                ("a_outer", C.c_int64), ("a_inner", C.c_int64), ("b_outer", C.c_int64), ("b_inner", C.c_int64),
+                ("c_outer", C.c_int64), ("c_inner", C.c_int64), ("alpha", C.c_float)]
+
+
 COMM_ID_BYTES = 128   # include/mdd_hip.h MDD_COMM_ID_BYTES
 
 _lib = None

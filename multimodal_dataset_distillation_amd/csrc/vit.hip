@@ -1,0 +1,538 @@
+// Building blocks of the ViT image encoder (BASELINE configs[4]): the operators a transformer
+// block has and an NFNet block does not -- LayerNorm over token rows, exact GELU, softmax rows and the batched
+// attention contractions -- each in the four forms the unrolled matching loop needs: forward, backward, and
+// (S = Dual) the tangents of both, obtained by running the SAME kernel body on dual numbers (common.h), exactly as
+// the NFNet elementwise kernels do.  Tangent calls read the primal operands and write ONLY the tangent outputs.
+// Reference: the reference reaches its transformers through timm / clip (networks.py:661,668); what is implemented
+// is timm 0.6.7's VisionTransformer block as restated in oracle/vit_ref.py.
+// Status: op-level entry points (include/mdd_hip.h `mdd_op_*`), parity-tested against torch; the engine topology
+// that walks them is the next step.
+#include <algorithm>
+
+#include "kernels.h"
+#include "mdd_hip.h"
+
+#define CHECK_ARG(cond, msg) \
+  do { if (!(cond)) return mdd_set_error_msg(2, "mdd: invalid argument: " msg); } while (0)
+
+namespace {
+
+template <class AT> DEVI void ldc(const AT* p, int64_t ci, float* f) {
+  uint4 v = ((const uint4*)p)[ci];
+  Chunk<AT>::unpack(v, f);
+}
+template <class AT> DEVI void stc(AT* p, int64_t ci, const float* f) { ((uint4*)p)[ci] = Chunk<AT>::pack(f); }
+template <class S, class AT> DEVI void ldcS(const AT* pv, const AT* pt, int64_t ci, S* out) {
+  constexpr int CE = Chunk<AT>::N;
+  float a[CE], b[CE];
+  ldc<AT>(pv, ci, a);
+  if constexpr (IsDual<S>::v) {
+    ldc<AT>(pt, ci, b);
+#pragma unroll
+    for (int i = 0; i < CE; ++i) out[i] = Dual(a[i], b[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < CE; ++i) out[i] = a[i];
+  }
+}
+template <class S, class AT> DEVI void stcS(AT* pv, AT* pt, int64_t ci, const S* x) {   // Dual: the tangent only
+  constexpr int CE = Chunk<AT>::N;
+  float a[CE];
+#pragma unroll
+  for (int i = 0; i < CE; ++i) a[i] = IsDual<S>::v ? tan_(x[i]) : val(x[i]);
+  stc<AT>(IsDual<S>::v ? pt : pv, ci, a);
+}
+// fp32 parameter vectors (gamma, beta): four at a time
+template <class S> DEVI void ldp4(const float* pv, const float* pt, int64_t i, S* out) {
+  const float4 a = *(const float4*)(pv + i);
+  if constexpr (IsDual<S>::v) {
+    const float4 b = *(const float4*)(pt + i);
+    out[0] = Dual(a.x, b.x); out[1] = Dual(a.y, b.y); out[2] = Dual(a.z, b.z); out[3] = Dual(a.w, b.w);
+  } else {
+    out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w;
+  }
+}
+
+// ------------------------------------------------------------------ LayerNorm over rows of `dim` (a wave per row)
+// lane l owns chunks l, l+64, ... (MAXC of them at most): the whole row sits in registers between the two reductions
+template <class S, class AT, int MAXC>
+__global__ __launch_bounds__(256) void k_ln_fwd(const AT* __restrict__ x, const AT* __restrict__ x_t,
+                                                const float* __restrict__ g, const float* __restrict__ g_t,
+                                                const float* __restrict__ b, const float* __restrict__ b_t,
+                                                AT* __restrict__ y, AT* __restrict__ y_t, int rows, int dim, float eps) {
+  constexpr int CE = Chunk<AT>::N;
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;                       // wave-uniform
+  const int cch = dim / CE;
+  const float rd = 1.f / dim;
+  S v[MAXC][CE];
+  S sum = mk<S>(0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < cch) {
+      ldcS<S, AT>(x, x_t, (int64_t)row * cch + c, v[i]);
+#pragma unroll
+      for (int e = 0; e < CE; ++e) sum = sum + v[i][e];
+    }
+  }
+  const S mean = wave_sum(sum) * rd;
+  S sq = mk<S>(0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+    if (lane + 64 * i < cch) {
+#pragma unroll
+      for (int e = 0; e < CE; ++e) { const S d = v[i][e] - mean; sq = sq + d * d; }
+    }
+  const S rstd = rsqrt_(wave_sum(sq) * rd + eps);
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < cch) {
+      S o[CE];
+#pragma unroll
+      for (int e = 0; e < CE; e += 4) {
+        S gg[4], bb[4];
+        ldp4<S>(g, g_t, (int64_t)c * CE + e, gg);
+        ldp4<S>(b, b_t, (int64_t)c * CE + e, bb);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[e + k] = (v[i][e + k] - mean) * rstd * gg[k] + bb[k];
+      }
+      stcS<S, AT>(y, y_t, (int64_t)row * cch + c, o);
+    }
+  }
+}
+
+// dx = rstd * (gy - mean(gy) - xh * mean(gy * xh)), gy = dy * gamma, xh = (x - mean) * rstd;
+// dgamma += sum_rows dy * xh, dbeta += sum_rows dy (per-block partial sums over its rows, then fp32 atomics).
+// The statistics are recomputed from x (x is read anyway).
+template <class S, class AT, int MAXC>
+__global__ __launch_bounds__(256) void k_ln_bwd(const AT* __restrict__ x, const AT* __restrict__ x_t,
+                                                const AT* __restrict__ dy, const AT* __restrict__ dy_t,
+                                                const float* __restrict__ g, const float* __restrict__ g_t,
+                                                AT* __restrict__ dx, AT* __restrict__ dx_t, float* __restrict__ dg,
+                                                float* __restrict__ dg_t, float* __restrict__ db,
+                                                float* __restrict__ db_t, int rows, int dim, float eps,
+                                                int rows_per_block) {
+  constexpr int CE = Chunk<AT>::N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cch = dim / CE;
+  const float rd = 1.f / dim;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  S gam[MAXC][CE], ag[MAXC][CE], ab[MAXC][CE];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { ag[i][e] = mk<S>(0.f, 0.f); ab[i][e] = mk<S>(0.f, 0.f); gam[i][e] = mk<S>(0.f, 0.f); }
+    if (c < cch) {
+#pragma unroll
+      for (int e = 0; e < CE; e += 4) ldp4<S>(g, g_t, (int64_t)c * CE + e, &gam[i][e]);
+    }
+  }
+  for (int row = r0 + wave; row < r1; row += 4) {
+    S v[MAXC][CE], d[MAXC][CE];
+    S sum = mk<S>(0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < cch) {
+        ldcS<S, AT>(x, x_t, (int64_t)row * cch + c, v[i]);
+        ldcS<S, AT>(dy, dy_t, (int64_t)row * cch + c, d[i]);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) sum = sum + v[i][e];
+      }
+    }
+    const S mean = wave_sum(sum) * rd;
+    S sq = mk<S>(0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+      if (lane + 64 * i < cch) {
+#pragma unroll
+        for (int e = 0; e < CE; ++e) { const S t = v[i][e] - mean; sq = sq + t * t; }
+      }
+    const S rstd = rsqrt_(wave_sum(sq) * rd + eps);
+    S s1 = mk<S>(0.f, 0.f), s2 = mk<S>(0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+      if (lane + 64 * i < cch) {
+#pragma unroll
+        for (int e = 0; e < CE; ++e) {
+          v[i][e] = (v[i][e] - mean) * rstd;                 // xh
+          ag[i][e] = ag[i][e] + d[i][e] * v[i][e];
+          ab[i][e] = ab[i][e] + d[i][e];
+          d[i][e] = d[i][e] * gam[i][e];                     // gy
+          s1 = s1 + d[i][e];
+          s2 = s2 + d[i][e] * v[i][e];
+        }
+      }
+    const S m1 = wave_sum(s1) * rd, m2 = wave_sum(s2) * rd;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < cch) {
+        S o[CE];
+#pragma unroll
+        for (int e = 0; e < CE; ++e) o[e] = rstd * (d[i][e] - m1 - v[i][e] * m2);
+        stcS<S, AT>(dx, dx_t, (int64_t)row * cch + c, o);
+      }
+    }
+  }
+  // the four waves' column sums -> one atomic per column and block.  Dual: the tangent sums only (the primal sums
+  // were produced by the primal call)
+  __shared__ float red[4][64 * MAXC * CE + 1];
+  auto reduce_to = [&](S (&acc)[MAXC][CE], float* outp) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+      for (int e = 0; e < CE; ++e) red[wave][(i * 64 + lane) * CE + e] = IsDual<S>::v ? tan_(acc[i][e]) : val(acc[i][e]);
+    __syncthreads();
+    for (int o = threadIdx.x; o < 64 * MAXC * CE; o += 256) {
+      const int e = o % CE, slot = o / CE, i = slot / 64, l = slot - i * 64;
+      const int c = l + 64 * i;
+      if (c < cch) atomicAdd(outp + (int64_t)c * CE + e, red[0][o] + red[1][o] + red[2][o] + red[3][o]);
+    }
+  };
+  reduce_to(ag, IsDual<S>::v ? dg_t : dg);
+  reduce_to(ab, IsDual<S>::v ? db_t : db);
+}
+
+// ------------------------------------------------------------------ exact GELU on chunks
+template <class S, class AT>
+__global__ void k_gelu_fwd(const AT* __restrict__ c, const AT* __restrict__ c_t, AT* __restrict__ a,
+                           AT* __restrict__ a_t, int64_t chunks) {
+  constexpr int CE = Chunk<AT>::N;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < chunks; i += (int64_t)gridDim.x * blockDim.x) {
+    S x[CE], o[CE];
+    ldcS<S, AT>(c, c_t, i, x);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) o[e] = gelu_(x[e]);
+    stcS<S, AT>(a, a_t, i, o);
+  }
+}
+template <class S, class AT>
+__global__ void k_gelu_bwd(const AT* __restrict__ c, const AT* __restrict__ c_t, const AT* __restrict__ ab,
+                           const AT* __restrict__ ab_t, AT* __restrict__ cb, AT* __restrict__ cb_t, int64_t chunks) {
+  constexpr int CE = Chunk<AT>::N;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < chunks; i += (int64_t)gridDim.x * blockDim.x) {
+    S x[CE], g[CE], o[CE];
+    ldcS<S, AT>(c, c_t, i, x);
+    ldcS<S, AT>(ab, ab_t, i, g);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) o[e] = g[e] * dgelu_(x[e]);
+    stcS<S, AT>(cb, cb_t, i, o);
+  }
+}
+
+// ------------------------------------------------------------------ softmax over rows of fp32 scores (a wave per row)
+constexpr int SM_MAXE = 8;     // columns per lane: cols <= 512
+template <class S>
+__global__ __launch_bounds__(256) void k_softmax_fwd(const float* __restrict__ s, const float* __restrict__ s_t,
+                                                     float* __restrict__ p, float* __restrict__ p_t, int64_t rows,
+                                                     int cols, int ld, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  S v[SM_MAXE];
+  float m = -3.0e38f;
+#pragma unroll
+  for (int i = 0; i < SM_MAXE; ++i) {
+    const int c = lane + 64 * i;
+    if (c < cols) { v[i] = ldS<S>(s, s_t, (size_t)(row * ld + c)); m = fmaxf(m, val(v[i])); }
+  }
+  m = wave_max(m);                                  // the shift is a constant of the row: it carries no tangent
+  S sum = mk<S>(0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < SM_MAXE; ++i)
+    if (lane + 64 * i < cols) { v[i] = exp_((v[i] - m) * scale); sum = sum + v[i]; }
+  sum = wave_sum(sum);
+#pragma unroll
+  for (int i = 0; i < SM_MAXE; ++i) {
+    const int c = lane + 64 * i;
+    if (c < cols) stS<S>(p, p_t, (size_t)(row * ld + c), v[i] / sum);
+  }
+}
+// ds = scale * p * (dp - sum_j p_j dp_j)
+template <class S>
+__global__ __launch_bounds__(256) void k_softmax_bwd(const float* __restrict__ p, const float* __restrict__ p_t,
+                                                     const float* __restrict__ dp, const float* __restrict__ dp_t,
+                                                     float* __restrict__ ds, float* __restrict__ ds_t, int64_t rows,
+                                                     int cols, int ld, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  S pv[SM_MAXE], dv[SM_MAXE];
+  S dot = mk<S>(0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < SM_MAXE; ++i) {
+    const int c = lane + 64 * i;
+    if (c < cols) {
+      pv[i] = ldS<S>(p, p_t, (size_t)(row * ld + c));
+      dv[i] = ldS<S>(dp, dp_t, (size_t)(row * ld + c));
+      dot = dot + pv[i] * dv[i];
+    }
+  }
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int i = 0; i < SM_MAXE; ++i) {
+    const int c = lane + 64 * i;
+    if (c < cols) stS<S>(ds, ds_t, (size_t)(row * ld + c), pv[i] * (dv[i] - dot) * scale);
+  }
+}
+
+// ------------------------------------------------------------------ strided batched contraction, S-generic
+// C[b](i, j) = alpha * sum_k A[b](i, k) * B[b](k, j), batch b = (o, q) with o < outer, q < inner; every operand is
+// addressed by element strides, so transposes and the head slices of a fused qkv tensor need no copies.
+// Dual: C_t = alpha * (A_t B + A B_t); a null tangent pointer is a zero tangent.
+struct BG {
+  const void *A, *A_t, *B, *B_t;
+  void *C, *C_t;
+  int M, N, K, inner;
+  int64_t sam, sak, sbk, sbn, scm, scn;     // element strides
+  int64_t ao, aq, bo, bq, co, cq;           // batch strides (outer, inner)
+  float alpha;
+};
+template <class S, class T> DEVI S ldS0(const T* pv, const T* pt, int64_t i) {
+  if constexpr (IsDual<S>::v) return Dual(to_f(pv[i]), pt ? to_f(pt[i]) : 0.f);
+  else return to_f(pv[i]);
+}
+template <class S, class TA, class TB, class TC>
+__global__ __launch_bounds__(256) void k_bgemm(const BG p) {
+  constexpr int BM = 64, BN = 64, BK = 16;
+  __shared__ float As[IsDual<S>::v ? 2 : 1][BK][BM + 1];
+  __shared__ float Bs[IsDual<S>::v ? 2 : 1][BK][BN + 1];
+  const int b = blockIdx.z, o = b / p.inner, q = b - o * p.inner;
+  const TA* A = (const TA*)p.A + o * p.ao + q * p.aq;
+  const TA* At = p.A_t ? (const TA*)p.A_t + o * p.ao + q * p.aq : nullptr;
+  const TB* B = (const TB*)p.B + o * p.bo + q * p.bq;
+  const TB* Bt = p.B_t ? (const TB*)p.B_t + o * p.bo + q * p.bq : nullptr;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  S acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = mk<S>(0.f, 0.f);
+  for (int k0 = 0; k0 < p.K; k0 += BK) {
+    // stage 16 x 64 of each operand: thread -> (k = tid / 16, four consecutive m / n)
+    for (int t = tid; t < BK * BM; t += 256) {
+      const int kk = t / BM, mm = t - kk * BM;
+      const int gm = m0 + mm, gk = k0 + kk;
+      S a = mk<S>(0.f, 0.f);
+      if (gm < p.M && gk < p.K) a = ldS0<S>(A, At, gm * p.sam + gk * p.sak);
+      As[0][kk][mm] = val(a);
+      if constexpr (IsDual<S>::v) As[1][kk][mm] = tan_(a);
+    }
+    for (int t = tid; t < BK * BN; t += 256) {
+      const int kk = t / BN, nn = t - kk * BN;
+      const int gn = n0 + nn, gk = k0 + kk;
+      S bb = mk<S>(0.f, 0.f);
+      if (gn < p.N && gk < p.K) bb = ldS0<S>(B, Bt, gk * p.sbk + gn * p.sbn);
+      Bs[0][kk][nn] = val(bb);
+      if constexpr (IsDual<S>::v) Bs[1][kk][nn] = tan_(bb);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK; ++kk) {
+      S a[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = mk<S>(As[0][kk][ty * 4 + i], IsDual<S>::v ? As[IsDual<S>::v ? 1 : 0][kk][ty * 4 + i] : 0.f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = mk<S>(Bs[0][kk][tx * 4 + j], IsDual<S>::v ? Bs[IsDual<S>::v ? 1 : 0][kk][tx * 4 + j] : 0.f);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = acc[i][j] + a[i] * bv[j];
+    }
+    __syncthreads();
+  }
+  TC* C = (TC*)(IsDual<S>::v ? p.C_t : p.C) + o * p.co + q * p.cq;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gm = m0 + ty * 4 + i, gn = n0 + tx * 4 + j;
+      if (gm < p.M && gn < p.N) {
+        const float r = (IsDual<S>::v ? tan_(acc[i][j]) : val(acc[i][j])) * p.alpha;
+        C[gm * p.scm + gn * p.scn] = from_f<TC>(r);
+      }
+    }
+}
+
+inline int vgrid(int64_t items, int block = 256) {
+  int64_t g = (items + block - 1) / block;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(g, 8192));
+}
+
+template <class AT>
+int ln_fwd(int rows, int dim, float eps, const void* x, const void* x_t, const float* g, const float* g_t,
+           const float* b, const float* b_t, void* y, void* y_t, hipStream_t st) {
+  const int cch = dim / Chunk<AT>::N, maxc = (cch + 63) / 64;
+  const int grid = (rows + 3) / 4;
+#define LN_F(MC)                                                                                                \
+  do {                                                                                                          \
+    if (x_t) k_ln_fwd<Dual, AT, MC><<<grid, 256, 0, st>>>((const AT*)x, (const AT*)x_t, g, g_t, b, b_t, (AT*)y,  \
+                                                          (AT*)y_t, rows, dim, eps);                            \
+    else k_ln_fwd<float, AT, MC><<<grid, 256, 0, st>>>((const AT*)x, nullptr, g, nullptr, b, nullptr, (AT*)y,    \
+                                                       nullptr, rows, dim, eps);                                \
+  } while (0)
+  if (maxc == 1) LN_F(1); else if (maxc == 2) LN_F(2); else if (maxc == 3) LN_F(3); else LN_F(4);
+#undef LN_F
+  return 0;
+}
+template <class AT>
+int ln_bwd(int rows, int dim, float eps, const void* x, const void* x_t, const void* dy, const void* dy_t,
+           const float* g, const float* g_t, void* dx, void* dx_t, float* dg, float* dg_t, float* db, float* db_t,
+           hipStream_t st) {
+  const int cch = dim / Chunk<AT>::N, maxc = (cch + 63) / 64;
+  const int rpb = 64, grid = (rows + rpb - 1) / rpb;
+#define LN_B(MC)                                                                                                 \
+  do {                                                                                                           \
+    if (x_t) k_ln_bwd<Dual, AT, MC><<<grid, 256, 0, st>>>((const AT*)x, (const AT*)x_t, (const AT*)dy,            \
+                                                          (const AT*)dy_t, g, g_t, (AT*)dx, (AT*)dx_t, dg, dg_t,  \
+                                                          db, db_t, rows, dim, eps, rpb);                        \
+    else k_ln_bwd<float, AT, MC><<<grid, 256, 0, st>>>((const AT*)x, nullptr, (const AT*)dy, nullptr, g, nullptr, \
+                                                       (AT*)dx, nullptr, dg, nullptr, db, nullptr, rows, dim,    \
+                                                       eps, rpb);                                                \
+  } while (0)
+  if (maxc == 1) LN_B(1); else if (maxc == 2) LN_B(2); else LN_B(3);
+#undef LN_B
+  return 0;
+}
+template <class S, class AT>
+void bgemm_types(const BG& p, int a_is_f32, int c_is_f32, dim3 grid, hipStream_t st) {
+  // operand types in use: (A, B, C) = (AT, AT, fp32) scores / score gradients; (fp32, AT, AT) everything that
+  // multiplies by the probabilities or their gradients
+  if (!a_is_f32 && c_is_f32) k_bgemm<S, AT, AT, float><<<grid, 256, 0, st>>>(p);
+  else if (a_is_f32 && !c_is_f32) k_bgemm<S, float, AT, AT><<<grid, 256, 0, st>>>(p);
+  else k_bgemm<S, AT, AT, AT><<<grid, 256, 0, st>>>(p);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdd_op_layernorm(int dtype, int rows, int dim, float eps, const void* x, const void* x_t, const float* gamma,
+                     const float* gamma_t, const float* beta, const float* beta_t, void* y, void* y_t, void* stream) {
+  CHECK_ARG(rows > 0 && dim > 0 && x && gamma && beta, "null pointer / empty problem");
+  CHECK_ARG((x_t != nullptr) == (gamma_t != nullptr) && (x_t != nullptr) == (beta_t != nullptr) &&
+                (x_t != nullptr) == (y_t != nullptr), "tangent operands come together");
+  CHECK_ARG(x_t || y, "output is null");
+  CHECK_ARG(dtype == MDD_DTYPE_F32 || dtype == MDD_DTYPE_BF16, "dtype");
+  const int ce = dtype == MDD_DTYPE_F32 ? 4 : 8;
+  CHECK_ARG(dim % ce == 0 && dim / ce <= 256, "dim must be a multiple of the 16-byte chunk and at most 256 chunks");
+  if (dtype == MDD_DTYPE_F32) ln_fwd<float>(rows, dim, eps, x, x_t, gamma, gamma_t, beta, beta_t, y, y_t, (hipStream_t)stream);
+  else ln_fwd<bf16>(rows, dim, eps, x, x_t, gamma, gamma_t, beta, beta_t, y, y_t, (hipStream_t)stream);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int mdd_op_layernorm_bwd(int dtype, int rows, int dim, float eps, const void* x, const void* x_t, const void* dy,
+                         const void* dy_t, const float* gamma, const float* gamma_t, void* dx, void* dx_t,
+                         float* dgamma, float* dgamma_t, float* dbeta, float* dbeta_t, void* stream) {
+  CHECK_ARG(rows > 0 && dim > 0 && x && dy && gamma, "null pointer / empty problem");
+  const bool T = x_t != nullptr;
+  CHECK_ARG(T == (dy_t != nullptr) && T == (gamma_t != nullptr) && T == (dx_t != nullptr) &&
+                T == (dgamma_t != nullptr) && T == (dbeta_t != nullptr), "tangent operands come together");
+  CHECK_ARG(T || (dx && dgamma && dbeta), "output is null");
+  CHECK_ARG(dtype == MDD_DTYPE_F32 || dtype == MDD_DTYPE_BF16, "dtype");
+  const int ce = dtype == MDD_DTYPE_F32 ? 4 : 8;
+  CHECK_ARG(dim % ce == 0 && dim / ce <= 192, "dim must be a multiple of the 16-byte chunk and at most 192 chunks");
+  if (dtype == MDD_DTYPE_F32) ln_bwd<float>(rows, dim, eps, x, x_t, dy, dy_t, gamma, gamma_t, dx, dx_t, dgamma, dgamma_t, dbeta, dbeta_t, (hipStream_t)stream);
+  else ln_bwd<bf16>(rows, dim, eps, x, x_t, dy, dy_t, gamma, gamma_t, dx, dx_t, dgamma, dgamma_t, dbeta, dbeta_t, (hipStream_t)stream);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int mdd_op_gelu(int dtype, int64_t n, const void* c, const void* c_t, void* a, void* a_t, void* stream) {
+  CHECK_ARG(n > 0 && c && (c_t ? a_t != nullptr : a != nullptr), "null pointer / empty problem");
+  CHECK_ARG(dtype == MDD_DTYPE_F32 || dtype == MDD_DTYPE_BF16, "dtype");
+  const int ce = dtype == MDD_DTYPE_F32 ? 4 : 8;
+  CHECK_ARG(n % ce == 0, "element count must be a multiple of the 16-byte chunk");
+  const int64_t ch = n / ce;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MDD_DTYPE_F32) {
+    if (c_t) k_gelu_fwd<Dual, float><<<vgrid(ch), 256, 0, st>>>((const float*)c, (const float*)c_t, (float*)a, (float*)a_t, ch);
+    else k_gelu_fwd<float, float><<<vgrid(ch), 256, 0, st>>>((const float*)c, nullptr, (float*)a, nullptr, ch);
+  } else {
+    if (c_t) k_gelu_fwd<Dual, bf16><<<vgrid(ch), 256, 0, st>>>((const bf16*)c, (const bf16*)c_t, (bf16*)a, (bf16*)a_t, ch);
+    else k_gelu_fwd<float, bf16><<<vgrid(ch), 256, 0, st>>>((const bf16*)c, nullptr, (bf16*)a, nullptr, ch);
+  }
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int mdd_op_gelu_bwd(int dtype, int64_t n, const void* c, const void* c_t, const void* abar, const void* abar_t,
+                    void* cbar, void* cbar_t, void* stream) {
+  CHECK_ARG(n > 0 && c && abar, "null pointer / empty problem");
+  const bool T = c_t != nullptr;
+  CHECK_ARG(T == (abar_t != nullptr) && (T ? cbar_t != nullptr : cbar != nullptr), "tangent operands come together");
+  CHECK_ARG(dtype == MDD_DTYPE_F32 || dtype == MDD_DTYPE_BF16, "dtype");
+  const int ce = dtype == MDD_DTYPE_F32 ? 4 : 8;
+  CHECK_ARG(n % ce == 0, "element count must be a multiple of the 16-byte chunk");
+  const int64_t ch = n / ce;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MDD_DTYPE_F32) {
+    if (T) k_gelu_bwd<Dual, float><<<vgrid(ch), 256, 0, st>>>((const float*)c, (const float*)c_t, (const float*)abar, (const float*)abar_t, (float*)cbar, (float*)cbar_t, ch);
+    else k_gelu_bwd<float, float><<<vgrid(ch), 256, 0, st>>>((const float*)c, nullptr, (const float*)abar, nullptr, (float*)cbar, nullptr, ch);
+  } else {
+    if (T) k_gelu_bwd<Dual, bf16><<<vgrid(ch), 256, 0, st>>>((const bf16*)c, (const bf16*)c_t, (const bf16*)abar, (const bf16*)abar_t, (bf16*)cbar, (bf16*)cbar_t, ch);
+    else k_gelu_bwd<float, bf16><<<vgrid(ch), 256, 0, st>>>((const bf16*)c, nullptr, (const bf16*)abar, nullptr, (bf16*)cbar, nullptr, ch);
+  }
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int mdd_op_softmax(int64_t rows, int cols, int ld, float scale, const float* s, const float* s_t, float* p,
+                   float* p_t, void* stream) {
+  CHECK_ARG(rows > 0 && cols > 0 && cols <= 64 * SM_MAXE && ld >= cols && s, "rows / cols (<= 512) / ld");
+  CHECK_ARG(s_t ? p_t != nullptr : p != nullptr, "output is null");
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  if (s_t) k_softmax_fwd<Dual><<<grid, 256, 0, (hipStream_t)stream>>>(s, s_t, p, p_t, rows, cols, ld, scale);
+  else k_softmax_fwd<float><<<grid, 256, 0, (hipStream_t)stream>>>(s, nullptr, p, nullptr, rows, cols, ld, scale);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int mdd_op_softmax_bwd(int64_t rows, int cols, int ld, float scale, const float* p, const float* p_t,
+                       const float* dp, const float* dp_t, float* ds, float* ds_t, void* stream) {
+  CHECK_ARG(rows > 0 && cols > 0 && cols <= 64 * SM_MAXE && ld >= cols && p && dp, "rows / cols (<= 512) / ld");
+  const bool T = p_t != nullptr;
+  CHECK_ARG(T == (dp_t != nullptr) && (T ? ds_t != nullptr : ds != nullptr), "tangent operands come together");
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  if (T) k_softmax_bwd<Dual><<<grid, 256, 0, (hipStream_t)stream>>>(p, p_t, dp, dp_t, ds, ds_t, rows, cols, ld, scale);
+  else k_softmax_bwd<float><<<grid, 256, 0, (hipStream_t)stream>>>(p, nullptr, dp, nullptr, ds, nullptr, rows, cols, ld, scale);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int mdd_op_bgemm(int dtype, int a_is_f32, int c_is_f32, const mdd_bgemm_desc* d, const void* A, const void* A_t,
+                 const void* B, const void* B_t, void* C, void* C_t, void* stream) {
+  CHECK_ARG(d && A && B, "null pointer");
+  CHECK_ARG(d->m > 0 && d->n > 0 && d->k > 0 && d->outer > 0 && d->inner > 0, "empty problem");
+  CHECK_ARG((int64_t)d->outer * d->inner <= 65535, "more than 65535 batches");
+  CHECK_ARG(dtype == MDD_DTYPE_F32 || dtype == MDD_DTYPE_BF16, "dtype");
+  const bool T = C_t != nullptr;
+  CHECK_ARG(T || C, "output is null");
+  CHECK_ARG(!T || A_t || B_t, "a tangent call needs at least one tangent operand");
+  BG p;
+  p.A = A; p.A_t = A_t; p.B = B; p.B_t = B_t; p.C = C; p.C_t = C_t;
+  p.M = d->m; p.N = d->n; p.K = d->k; p.inner = d->inner;
+  p.sam = d->a_row; p.sak = d->a_col; p.sbk = d->b_row; p.sbn = d->b_col; p.scm = d->c_row; p.scn = d->c_col;
+  p.ao = d->a_outer; p.aq = d->a_inner; p.bo = d->b_outer; p.bq = d->b_inner; p.co = d->c_outer; p.cq = d->c_inner;
+  p.alpha = d->alpha;
+  dim3 grid((unsigned)((d->n + 63) / 64), (unsigned)((d->m + 63) / 64), (unsigned)(d->outer * d->inner));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MDD_DTYPE_F32) {
+    if (T) k_bgemm<Dual, float, float, float><<<grid, 256, 0, st>>>(p);
+    else k_bgemm<float, float, float, float><<<grid, 256, 0, st>>>(p);
+  } else {
+    if (T) bgemm_types<Dual, bf16>(p, a_is_f32, c_is_f32, grid, st);
+    else bgemm_types<float, bf16>(p, a_is_f32, c_is_f32, grid, st);
+  }
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -188,3 +188,25 @@ def test_bench_algorithmic_flops_match_the_network_spec():
     want = 8 * 9 * 2 * (100 * (macs[0] + head) + 100 * 100 * 2304)
     assert abs(bench.algorithmic_flops_per_iter(100, 8) - want) / want < 1e-3
     assert abs(bench.algorithmic_flops_per_iter(100, 8) - 61.2e12) / 61.2e12 < 2e-3
+
+
+def test_vit_structural_anchors():
+    """oracle/vit_ref.py restates timm 0.6.7's VisionTransformer (parity unpinned: timm is absent).  What CAN be
+    checked: the published parameter counts (with timm's 1000-way head) and the flatten order ReparamModule gives."""
+    from oracle import vit_ref as vr, distill_ref as dr
+    enc = vr.ImageEncoder("vit_b16")
+    n = sum(p.numel() for p in enc.parameters())
+    assert n == 85_798_656 and n + 768 * 1000 + 1000 == 86_567_656          # vit_base_patch16_224: 86.6 M
+    assert enc.model.num_features == 768 and enc.model.num_tokens == 197
+    tiny = vr.ImageEncoder("vit_tiny16")
+    nt = sum(p.numel() for p in tiny.parameters())
+    assert nt + 192 * 1000 + 1000 == 5_717_416                               # vit_tiny_patch16_224: 5.7 M
+    fm = dr.FlatModule(vr.ImageEncoder("vit_micro"))
+    assert fm.names[:4] == ["model.cls_token", "model.pos_embed", "model.patch_embed.proj.weight",
+                            "model.patch_embed.proj.bias"]
+    assert fm.names[4:16] == ["model.blocks.0." + s for s in (
+        "norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
+        "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")]
+    assert fm.names[-2:] == ["model.norm.weight", "model.norm.bias"]
+    x = torch.randn(3, 3, 32, 32)
+    assert fm(x, flat_param=fm.flat_param()).shape == (3, 64)
