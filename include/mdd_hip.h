@@ -238,7 +238,8 @@ int mdd_allreduce_syn_grads(mdd_comm* c, float* buf_dev, int64_t n, int average,
  * primal operands and writes ONLY the `*_t` outputs.  dtype: MDD_DTYPE_F32 or MDD_DTYPE_BF16 = the storage type of
  * the activation tensors (`void*`); parameters, scores and probabilities are fp32.  Row-major, 16-byte aligned.
  *   layernorm      y = (x - mean) * rstd * gamma + beta over rows of `dim`            (eps 1e-6 in ViT)
- *   layernorm_bwd  dx, and dgamma / dbeta ACCUMULATED (+=, fp32 atomics) into the caller's zeroed/partial sums
+ *   layernorm_bwd  dx (+ `res` when non-NULL: the gradient arriving over the residual connection), and dgamma / dbeta
+ *                  ACCUMULATED (+=, fp32 atomics) into the caller's zeroed/partial sums
  *   gelu           a = GELU(c) (exact, erf);  gelu_bwd  cbar = abar * GELU'(c)
  *   softmax        p = softmax(scale * s) over `cols` of each row (row stride ld); softmax_bwd  ds = scale*p*(dp - <p,dp>)
  *   bgemm          C[b] = alpha * A[b] B[b] for b = (o < outer, q < inner), every operand addressed by element strides
@@ -253,8 +254,9 @@ typedef struct mdd_bgemm_desc {
 int mdd_op_layernorm(int dtype, int rows, int dim, float eps, const void* x, const void* x_t, const float* gamma,
                      const float* gamma_t, const float* beta, const float* beta_t, void* y, void* y_t, void* stream);
 int mdd_op_layernorm_bwd(int dtype, int rows, int dim, float eps, const void* x, const void* x_t, const void* dy,
-                         const void* dy_t, const float* gamma, const float* gamma_t, void* dx, void* dx_t,
-                         float* dgamma, float* dgamma_t, float* dbeta, float* dbeta_t, void* stream);
+                         const void* dy_t, const float* gamma, const float* gamma_t, const void* res,
+                         const void* res_t, void* dx, void* dx_t, float* dgamma, float* dgamma_t, float* dbeta,
+                         float* dbeta_t, void* stream);
 int mdd_op_gelu(int dtype, int64_t n, const void* c, const void* c_t, void* a, void* a_t, void* stream);
 int mdd_op_gelu_bwd(int dtype, int64_t n, const void* c, const void* c_t, const void* abar, const void* abar_t,
                     void* cbar, void* cbar_t, void* stream);

@@ -86,6 +86,15 @@ bool get_cfg(const char* variant, NfCfg& c) {
   return false;
 }
 
+// ViT topology (BASELINE configs[4]; timm 0.6.7 VisionTransformer as restated in oracle/vit_ref.py)
+struct VitCfg { int patch, dim, depth, heads; float eps; };
+bool get_vit_cfg(const char* variant, VitCfg& c) {
+  if (!strcmp(variant, "vit_b16")) { c = {16, 768, 12, 12, 1e-6f}; return true; }      // vit_base_patch16_224
+  if (!strcmp(variant, "vit_tiny16")) { c = {16, 192, 12, 3, 1e-6f}; return true; }    // vit_tiny_patch16_224 (networks.py:668)
+  if (!strcmp(variant, "vit_micro")) { c = {8, 64, 2, 2, 1e-6f}; return true; }        // build-defined miniature (tests)
+  return false;
+}
+
 struct ParamInfo { std::string name; int64_t shape[4]; int ndim; int64_t offset, numel; };
 
 struct ConvL {
@@ -94,8 +103,10 @@ struct ConvL {
   int cin_pad;            // total input channels as stored (conv1: 8)
   int64_t off_w, off_b, off_g;
   int64_t off_p;          // offset into packed buffers (same for wf / wt / dwf)
+  int tokens = 0;         // > 0: a linear over batch*tokens rows (ViT), no spatial extent
   int64_t packed() const { return (int64_t)cout * k * k * (cin_pad / groups); }
 };
+struct VitBlkL { int qkv, proj, fc1, fc2; int64_t ln1_w, ln1_b, ln2_w, ln2_b; };
 struct SeL { int c, rd; int64_t off_w1, off_b1, off_w2, off_b2; };
 struct Blk {
   int ds, c1, c2, c2b, c3;  // conv indices (ds = -1: identity shortcut)
@@ -152,6 +163,12 @@ namespace {
 template <class AT>
 struct Eng : mdd_engine {
   NfCfg nf;
+  bool is_vit = false;     // the image encoder is a Vision Transformer (vit_forward / vit_backward below)
+  VitCfg vit;
+  int Tk = 0, sld = 0;     // tokens per image (1 + patches), row stride of the score / probability matrices
+  std::vector<VitBlkL> vblk;
+  int pe_conv = -1;
+  int64_t off_cls = 0, off_pos = 0, off_nw = 0, off_nb = 0;
   int prec = 0;   // ConvGeom::prec of every contraction (fp32 storage: 0 exact, 1 split-bf16, 2 hi only)
   int N, S, Dt, K;
   // Activation stash policy: steps k < keep own stash slot k; steps k >= keep share slot
@@ -175,7 +192,16 @@ struct Eng : mdd_engine {
     AT *C3B, *A2bB, *C2bB, *A2B, *C2B, *A1B, *C1B, *AinB;
     float *zB, *hB, *pB;
   };
+  struct VitActs {
+    AT *N1, *QKV, *O, *X2, *N2, *C, *A;       // LayerNorm 1, fused qkv, attention output, stream after attention, LayerNorm 2, fc1, GELU
+    float* P;                                 // attention probabilities [batch*heads*tokens, sld]
+    AT *N1B, *QKVB, *OB, *X2B, *N2B, *CB, *AB;
+    float *PB, *SB;                           // gradients of the probabilities / of the scores
+  };
   struct ActSet {
+    AT *VCOL = nullptr, *VPE = nullptr, *VCOLB = nullptr, *VPEB = nullptr;   // patch columns, patch embedding (+ grads)
+    AT *CLS = nullptr, *CLSN = nullptr, *CLSNB = nullptr, *CLSB = nullptr, *TMP = nullptr;
+    std::vector<VitActs> vb;
     AT* X0;
     AT *Cs[3], *As[3];
     std::vector<AT*> X, A, XB;  // stream, pre-activated stream, stream grads
@@ -221,7 +247,8 @@ struct Eng : mdd_engine {
   int build(const mdd_config& c) {
     cfg = c; variant = c.variant; cfg.variant = variant.c_str();
     N = c.batch; S = c.image_size; Dt = c.d_txt; K = c.syn_steps;
-    CHECK_ARG(get_cfg(c.variant, nf), "unknown variant");
+    is_vit = get_vit_cfg(c.variant, vit);
+    CHECK_ARG(is_vit || get_cfg(c.variant, nf), "unknown variant");
     CHECK_ARG(S % 32 == 0 && S >= 32, "image_size must be a multiple of 32");
     CHECK_ARG(N >= 2 && N <= 1024, "batch must be in [2,1024]");
     CHECK_ARG(K >= 1 && K <= 64, "syn_steps must be in [1,64]");
@@ -250,6 +277,45 @@ struct Eng : mdd_engine {
       convs.push_back(L);
       return (int)convs.size() - 1;
     };
+    if (is_vit) {
+      // timm registration order: cls_token, pos_embed, patch_embed.proj, blocks.i.{norm1, attn.qkv, attn.proj,
+      // norm2, mlp.fc1, mlp.fc2}, norm (oracle/vit_ref.py; reparam_module.py:28-39 flattens in this order)
+      CHECK_ARG(S % vit.patch == 0, "image_size must be a multiple of the patch size");
+      const int D = vit.dim, gp = S / vit.patch;
+      Tk = 1 + gp * gp; sld = (Tk + 3) & ~3;
+      CHECK_ARG(D % vit.heads == 0 && Tk <= 512, "heads must divide dim; at most 512 tokens");
+      auto add_lin = [&](const std::string& name, int cin, int cout, int tokens, bool conv_shape) {
+        ConvL L; L.cin = cin; L.cout = cout; L.k = 1; L.stride = 1; L.groups = 1; L.pad = 0;
+        L.hin = 1; L.hout = 1; L.cin_pad = cin; L.tokens = tokens;
+        if (conv_shape) L.off_w = add_param(pimg, name + ".weight", {cout, 3, vit.patch, vit.patch});
+        else L.off_w = add_param(pimg, name + ".weight", {cout, cin});
+        L.off_b = add_param(pimg, name + ".bias", {cout});
+        L.off_g = -1;
+        L.off_p = packed_total; packed_total += L.packed();
+        convs.push_back(L);
+        return (int)convs.size() - 1;
+      };
+      off_cls = add_param(pimg, "model.cls_token", {1, 1, D});
+      off_pos = add_param(pimg, "model.pos_embed", {1, Tk, D});
+      pe_conv = add_lin("model.patch_embed.proj", 3 * vit.patch * vit.patch, D, Tk - 1, true);
+      for (int l = 0; l < vit.depth; ++l) {
+        std::string pre = "model.blocks." + std::to_string(l);
+        VitBlkL B;
+        B.ln1_w = add_param(pimg, pre + ".norm1.weight", {D}); B.ln1_b = add_param(pimg, pre + ".norm1.bias", {D});
+        B.qkv = add_lin(pre + ".attn.qkv", D, 3 * D, Tk, false);
+        B.proj = add_lin(pre + ".attn.proj", D, D, Tk, false);
+        B.ln2_w = add_param(pimg, pre + ".norm2.weight", {D}); B.ln2_b = add_param(pimg, pre + ".norm2.bias", {D});
+        B.fc1 = add_lin(pre + ".mlp.fc1", D, 4 * D, Tk, false);
+        B.fc2 = add_lin(pre + ".mlp.fc2", 4 * D, D, Tk, false);
+        vblk.push_back(B);
+      }
+      off_nw = add_param(pimg, "model.norm.weight", {D}); off_nb = add_param(pimg, "model.norm.bias", {D});
+      int ce = 16 / (int)sizeof(AT);
+      CHECK_ARG(D % ce == 0 && (3 * vit.patch * vit.patch) % ce == 0 && (D / vit.heads) % 4 == 0,
+                "dims must be multiples of the 16-byte chunk");
+      P_img = off; feat = D;
+      stem[0] = stem[1] = stem[2] = stem[3] = fin = -1;
+    } else {
     // stem 'deep_quad': 3x3 convs, channels (sc/8, sc/4, sc/2, sc), strides (2,1,1,2)
     int sc = nf.stem_chs, chs[4] = {sc / 8, sc / 4, sc / 2, sc}, strides[4] = {2, 1, 1, 2};
     int prev = 3, h = S;
@@ -293,6 +359,7 @@ struct Eng : mdd_engine {
     feat = (int)(nf.channels[3] * nf.feat_mult);
     fin = add_conv("model.final_conv", prev, feat, 1, 1, 1, h);
     P_img = off;
+    }   // NFNet topology
     CHECK_ARG(feat <= 4096, "feature dim > 4096 unsupported by the contrastive head kernel");
     // text head (reference networks.py:625-646)
     off = 0;
@@ -307,6 +374,7 @@ struct Eng : mdd_engine {
     int row = 0, tile = 0;
     const int tr = ws_tile_rows();
     for (auto& L : convs) {
+      if (is_vit) break;      // plain linears: cast / transpose pack (vit_pack), no weight standardisation
       WsDesc d; d.off_w = L.off_w; d.off_b = L.off_b; d.off_g = L.off_g;
       d.off_wf = L.off_p; d.off_wt = L.off_p;
       d.cout = L.cout; d.cin_g = L.cin / L.groups; d.ksq = L.k * L.k; d.groups = L.groups;
@@ -323,7 +391,40 @@ struct Eng : mdd_engine {
     return 0;
   }
 
+  void plan_set_vit(ActSet& s, int slot) {
+    const int64_t n = N, D = vit.dim, M = n * Tk, kk = 3 * vit.patch * vit.patch, np = Tk - 1;
+    const int64_t pr = n * vit.heads * Tk * sld;
+    plan(&s.VCOL, n * np * kk, "vit.COL", slot); plan(&s.VPE, n * np * D, "vit.PE", slot);
+    plan(&s.VCOLB, n * np * kk, "vit.COLB", slot); plan(&s.VPEB, n * np * D, "vit.PEB", slot);
+    plan(&s.CLS, n * D, "vit.CLS", slot); plan(&s.CLSN, n * D, "vit.CLSN", slot);
+    plan(&s.CLSNB, n * D, "vit.CLSNB", slot); plan(&s.CLSB, n * D, "vit.CLSB", slot);
+    plan(&s.TMP, M * D, "vit.TMP", slot);
+    s.X.resize(vit.depth + 1); s.XB.resize(vit.depth + 1); s.vb.resize(vit.depth);
+    for (int l = 0; l <= vit.depth; ++l) {
+      plan(&s.X[l], M * D, ("X" + std::to_string(l)).c_str(), slot);
+      plan(&s.XB[l], M * D, ("XB" + std::to_string(l)).c_str(), slot);
+    }
+    for (int l = 0; l < vit.depth; ++l) {
+      VitActs& a = s.vb[l];
+      std::string p = "v" + std::to_string(l) + ".";
+      plan(&a.N1, M * D, (p + "N1").c_str(), slot);   plan(&a.QKV, M * 3 * D, (p + "QKV").c_str(), slot);
+      plan(&a.P, pr, (p + "P").c_str(), slot);        plan(&a.O, M * D, (p + "O").c_str(), slot);
+      plan(&a.X2, M * D, (p + "X2").c_str(), slot);   plan(&a.N2, M * D, (p + "N2").c_str(), slot);
+      plan(&a.C, M * 4 * D, (p + "C").c_str(), slot); plan(&a.A, M * 4 * D, (p + "A").c_str(), slot);
+      plan(&a.N1B, M * D, (p + "N1B").c_str(), slot); plan(&a.QKVB, M * 3 * D, (p + "QKVB").c_str(), slot);
+      plan(&a.PB, pr, (p + "PB").c_str(), slot);      plan(&a.SB, pr, (p + "SB").c_str(), slot);
+      plan(&a.OB, M * D, (p + "OB").c_str(), slot);   plan(&a.X2B, M * D, (p + "X2B").c_str(), slot);
+      plan(&a.N2B, M * D, (p + "N2B").c_str(), slot); plan(&a.CB, M * 4 * D, (p + "CB").c_str(), slot);
+      plan(&a.AB, M * 4 * D, (p + "AB").c_str(), slot);
+    }
+    plan(&s.y, n * feat, "y", slot); plan(&s.yB, n * feat, "yB", slot);
+    plan(&s.tx, n * Dt, "tx", slot); plan(&s.tp, n * feat, "tp", slot); plan(&s.tg, n * feat, "tg", slot);
+    plan(&s.tf, n * feat, "tf", slot); plan(&s.tr, n * feat, "tr", slot); plan(&s.ty, n * feat, "ty", slot);
+    plan(&s.tyB, n * feat, "tyB", slot); plan(&s.trB, n * feat, "trB", slot); plan(&s.tfB, n * feat, "tfB", slot);
+    plan(&s.tgB, n * feat, "tgB", slot); plan(&s.tpB, n * feat, "tpB", slot); plan(&s.txB, n * Dt, "txB", slot);
+  }
   void plan_set(ActSet& s, int slot) {
+    if (is_vit) { plan_set_vit(s, slot); return; }
     int nb = (int)blks.size();
     auto nm = [&](const std::string& n) { return n; };
     int64_t n = N;
@@ -442,8 +543,9 @@ struct Eng : mdd_engine {
     base = (char*)ws;
     for (auto& f : fix) *f.first = (void*)(base + f.second);
     d_descs = (WsDesc*)(base + o_descs);
-    HIP_CHECK_RET(hipMemcpyAsync(d_descs, descs.data(), descs.size() * sizeof(WsDesc),
-                                 hipMemcpyHostToDevice, st));
+    if (!descs.empty())
+      HIP_CHECK_RET(hipMemcpyAsync(d_descs, descs.data(), descs.size() * sizeof(WsDesc),
+                                   hipMemcpyHostToDevice, st));
     // packed weight buffers carry zero padding (conv1: 3 -> 8 input channels) that is never rewritten
     HIP_CHECK_RET(hipMemsetAsync(wf, 0, packed_total * sizeof(AT), st));
     HIP_CHECK_RET(hipMemsetAsync(wt, 0, packed_total * sizeof(AT), st));
@@ -474,13 +576,13 @@ struct Eng : mdd_engine {
 
   // ------------------------------------------------------------------ geometry helpers
   ConvGeom gfwd(const ConvL& L) const {
-    ConvGeom g; g.nimg = N; g.ha = L.hin; g.wa = L.hin; g.ca_tot = L.cin_pad;
+    ConvGeom g; g.nimg = L.tokens ? N * L.tokens : N; g.ha = L.hin; g.wa = L.hin; g.ca_tot = L.cin_pad;
     g.ho = L.hout; g.wo = L.hout; g.co_tot = L.cout; g.kc = L.cin_pad / L.groups;
     g.nc = L.cout / L.groups; g.groups = L.groups; g.k = L.k; g.stride = L.stride; g.pad = L.pad;
     g.transposed = 0; g.prec = prec; return g;
   }
   ConvGeom gdgrad(const ConvL& L) const {
-    ConvGeom g; g.nimg = N; g.ha = L.hout; g.wa = L.hout; g.ca_tot = L.cout;
+    ConvGeom g; g.nimg = L.tokens ? N * L.tokens : N; g.ha = L.hout; g.wa = L.hout; g.ca_tot = L.cout;
     g.ho = L.hin; g.wo = L.hin; g.co_tot = L.cin_pad; g.kc = L.cout / L.groups;
     g.nc = L.cin_pad / L.groups; g.groups = L.groups; g.k = L.k; g.stride = L.stride; g.pad = L.pad;
     g.transposed = 1; g.prec = prec; return g;
@@ -580,7 +682,7 @@ struct Eng : mdd_engine {
     return 0;
   }
   double conv_macs(const ConvL& L) const {
-    return (double)N * L.hout * L.hout * L.cout * (L.cin / L.groups) * L.k * L.k;
+    return (double)N * (L.tokens ? L.tokens : 1) * L.hout * L.hout * L.cout * (L.cin / L.groups) * L.k * L.k;
   }
   void gemm(const ConvL& L, const ConvGeom& g, const AT* A1, const AT* B1, const AT* A2, const AT* B2,
             const ConvEpi& e, hipStream_t st) {
@@ -690,12 +792,189 @@ struct Eng : mdd_engine {
     e.mode = EPI_BWD_LIN; e.out_raw = raw; e.add1 = add1; e.beta = 1.f; return e;
   }
 
+  // ================================================================== ViT image encoder (BASELINE configs[4])
+  // timm 0.6.7 VisionTransformer, class token as the feature (oracle/vit_ref.py).  The linears run on k_conv_gemm
+  // MODE 0 over batch*tokens rows (ConvL::tokens) with their weight gradients written by k_conv_wgrad straight
+  // into the flat gradient (a linear's packed layout is its parameter layout); LayerNorm / GELU / softmax / the
+  // attention contractions are the S-generic kernels of vit.hip (mdd_op_*), whose tangent calls write only `_t`.
+  static constexpr int VDT = sizeof(AT) == 4 ? MDD_DTYPE_F32 : MDD_DTYPE_BF16;
+  void vit_pack(const float* th, const float* th_t, hipStream_t st) {
+    for (auto& L : convs) {
+      launch_lin_pack<AT>(wf + L.off_p, wt + L.off_p, th + L.off_w, L.cout, L.cin, st);
+      if (th_t) launch_lin_pack<AT>(wf_t + L.off_p, wt_t + L.off_p, th_t + L.off_w, L.cout, L.cin, st);
+    }
+  }
+  // the weight gradient of a linear goes to gout + off_w: conv_bwd_w adds the layer's PACKED offset to its base
+  void lin_bwd_w(bool T, const ConvL& L, const AT* dy, const AT* dy_t, const AT* x, const AT* x_t, float* gout,
+                 hipStream_t st) {
+    float* basep = gout + (L.off_w - L.off_p);
+    conv_bwd_w(T, L, dy, dy_t, x, x_t, basep, basep, gout, st);
+  }
+  struct AttnDesc { mdd_bgemm_desc s, o, dp, dv, dq, dk; };
+  AttnDesc attn_desc() const {
+    const int64_t D = vit.dim, H = vit.heads, hd = D / H, R = 3 * D, T_ = Tk, ld = sld;
+    auto mk_ = [&](int m, int n, int k, int64_t ar, int64_t ac, int64_t ao, int64_t aq, int64_t br, int64_t bc,
+                   int64_t bo, int64_t bq, int64_t cr, int64_t cc, int64_t co, int64_t cq) {
+      mdd_bgemm_desc d; memset(&d, 0, sizeof d);
+      d.m = m; d.n = n; d.k = k; d.outer = N; d.inner = (int)H;
+      d.a_row = ar; d.a_col = ac; d.a_outer = ao; d.a_inner = aq;
+      d.b_row = br; d.b_col = bc; d.b_outer = bo; d.b_inner = bq;
+      d.c_row = cr; d.c_col = cc; d.c_outer = co; d.c_inner = cq; d.alpha = 1.f;
+      return d;
+    };
+    const int64_t po = H * T_ * ld, pq = T_ * ld;      // batch strides of the score matrices
+    AttnDesc a;
+    a.s = mk_(Tk, Tk, (int)hd, R, 1, T_ * R, hd, 1, R, T_ * R, hd, ld, 1, po, pq);        // q k^T
+    a.o = mk_(Tk, (int)hd, Tk, ld, 1, po, pq, R, 1, T_ * R, hd, D, 1, T_ * D, hd);         // p v
+    a.dp = mk_(Tk, Tk, (int)hd, D, 1, T_ * D, hd, 1, R, T_ * R, hd, ld, 1, po, pq);        // do v^T
+    a.dv = mk_(Tk, (int)hd, Tk, 1, ld, po, pq, D, 1, T_ * D, hd, R, 1, T_ * R, hd);        // p^T do
+    a.dq = mk_(Tk, (int)hd, Tk, ld, 1, po, pq, R, 1, T_ * R, hd, R, 1, T_ * R, hd);        // ds k
+    a.dk = mk_(Tk, (int)hd, Tk, 1, ld, po, pq, R, 1, T_ * R, hd, R, 1, T_ * R, hd);        // ds^T q
+    return a;
+  }
+#define VIT_RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+  int vit_forward(bool T, int slot, const float* th, const float* th_t, const float* image, const int64_t* idx,
+                  float* feat_out, hipStream_t st) {
+    ActSet& P = sets[slot]; ActSet& Q = tn;
+    const int D = vit.dim, M = N * Tk;
+    const int64_t rows = (int64_t)N * vit.heads * Tk;
+    const float scale = 1.f / std::sqrt((float)(D / vit.heads));
+    const AttnDesc ad = attn_desc();
+    auto tp = [&](const float* q) { return T ? q : (const float*)nullptr; };
+    vit_pack(th, T ? th_t : nullptr, st);
+    if (!T) launch_patchify<AT>(P.VCOL, image, idx, N, S, vit.patch, st);
+    conv_fwd(T, convs[pe_conv], P.VCOL, nullptr, P.VPE, Q.VPE, nullptr, nullptr, 1.f, th, th_t, st);
+    launch_vit_embed<AT>(P.X[0], T ? Q.X[0] : nullptr, P.VPE, T ? Q.VPE : nullptr, th + off_cls,
+                         tp(th_t + off_cls), th + off_pos, tp(th_t + off_pos), N, Tk, D, st);
+    for (int l = 0; l < vit.depth; ++l) {
+      const VitBlkL& B = vblk[l]; VitActs& pa = P.vb[l]; VitActs& qa = Q.vb[l];
+      const AT *x = P.X[l], *x_t = T ? Q.X[l] : nullptr;
+      VIT_RC(mdd_op_layernorm(VDT, M, D, vit.eps, x, x_t, th + B.ln1_w, tp(th_t + B.ln1_w), th + B.ln1_b,
+                              tp(th_t + B.ln1_b), pa.N1, T ? qa.N1 : nullptr, st));
+      conv_fwd(T, convs[B.qkv], pa.N1, qa.N1, pa.QKV, qa.QKV, nullptr, nullptr, 1.f, th, th_t, st);
+      // attention: scores -> probabilities (in place) -> weighted values.  Tangent of the softmax from the stashed
+      // probabilities: p_t = scale * p * (s_t - <p, s_t>) -- the softmax Jacobian is symmetric, so it is the
+      // backward kernel applied to the score tangent.
+      const AT *q = pa.QKV, *k = pa.QKV + D, *v = pa.QKV + 2 * D;
+      const AT *q_t = T ? qa.QKV : nullptr, *k_t = T ? qa.QKV + D : nullptr, *v_t = T ? qa.QKV + 2 * D : nullptr;
+      if (!T) {
+        VIT_RC(mdd_op_bgemm(VDT, 0, 1, &ad.s, q, nullptr, k, nullptr, pa.P, nullptr, st));
+        VIT_RC(mdd_op_softmax(rows, Tk, sld, scale, pa.P, nullptr, pa.P, nullptr, st));
+        VIT_RC(mdd_op_bgemm(VDT, 1, 0, &ad.o, pa.P, nullptr, v, nullptr, pa.O, nullptr, st));
+      } else {
+        VIT_RC(mdd_op_bgemm(VDT, 0, 1, &ad.s, q, q_t, k, k_t, nullptr, qa.P, st));
+        VIT_RC(mdd_op_softmax_bwd(rows, Tk, sld, scale, pa.P, nullptr, qa.P, nullptr, qa.P, nullptr, st));
+        VIT_RC(mdd_op_bgemm(VDT, 1, 0, &ad.o, pa.P, qa.P, v, v_t, nullptr, qa.O, st));
+      }
+      conv_fwd(T, convs[B.proj], pa.O, qa.O, P.TMP, Q.TMP, nullptr, nullptr, 1.f, th, th_t, st);
+      launch_add2<AT>(pa.X2, T ? qa.X2 : nullptr, x, x_t, P.TMP, T ? Q.TMP : nullptr, (int64_t)M * D, st);
+      VIT_RC(mdd_op_layernorm(VDT, M, D, vit.eps, pa.X2, T ? qa.X2 : nullptr, th + B.ln2_w, tp(th_t + B.ln2_w),
+                              th + B.ln2_b, tp(th_t + B.ln2_b), pa.N2, T ? qa.N2 : nullptr, st));
+      conv_fwd(T, convs[B.fc1], pa.N2, qa.N2, pa.C, qa.C, nullptr, nullptr, 1.f, th, th_t, st);
+      VIT_RC(mdd_op_gelu(VDT, (int64_t)M * 4 * D, pa.C, T ? qa.C : nullptr, pa.A, T ? qa.A : nullptr, st));
+      conv_fwd(T, convs[B.fc2], pa.A, qa.A, P.TMP, Q.TMP, nullptr, nullptr, 1.f, th, th_t, st);
+      launch_add2<AT>(P.X[l + 1], T ? Q.X[l + 1] : nullptr, pa.X2, T ? qa.X2 : nullptr, P.TMP, T ? Q.TMP : nullptr,
+                      (int64_t)M * D, st);
+    }
+    // feature = LayerNorm(x_L)[:, 0]: normalise the class rows only
+    launch_cls_gather<AT>(T ? Q.CLS : P.CLS, T ? Q.X[vit.depth] : P.X[vit.depth], N, Tk, D, st);
+    VIT_RC(mdd_op_layernorm(VDT, N, D, vit.eps, P.CLS, T ? Q.CLS : nullptr, th + off_nw, tp(th_t + off_nw),
+                            th + off_nb, tp(th_t + off_nb), P.CLSN, T ? Q.CLSN : nullptr, st));
+    if (!T) {
+      launch_act_to_f32<AT>(P.y, P.CLSN, (int64_t)N * D, st);
+      if (feat_out && feat_out != P.y)
+        HIP_CHECK_RET(hipMemcpyAsync(feat_out, P.y, (size_t)N * feat * 4, hipMemcpyDeviceToDevice, st));
+    } else {
+      launch_act_to_f32<AT>(feat_out, Q.CLSN, (int64_t)N * D, st);
+    }
+    POST_WALK("vit_forward");
+    return 0;
+  }
+  int vit_backward(bool T, int slot, const float* th, const float* th_t, const float* ybar_in,
+                   const float* ybar_t_in, float* gout, float* dimage, const int64_t* idx, const float* coef,
+                   float mul, bool repack, bool stash, hipStream_t st) {
+    ActSet& P = sets[slot]; ActSet& Q = tn;
+    ActSet& O = (!T && !stash) ? tn : P;       // where the primal backward signals are written
+    const int D = vit.dim, M = N * Tk, L_ = vit.depth;
+    const int64_t rows = (int64_t)N * vit.heads * Tk;
+    const float scale = 1.f / std::sqrt((float)(D / vit.heads));
+    const AttnDesc ad = attn_desc();
+    auto tp = [&](const float* q) { return T ? q : (const float*)nullptr; };
+    // gradient slices: a primal call fills gout with d/d theta, a tangent call with its tangent
+    auto gp = [&](int64_t off) { return T ? (float*)nullptr : gout + off; };
+    auto gt = [&](int64_t off) { return T ? gout + off : (float*)nullptr; };
+    if (repack) vit_pack(th, T ? th_t : nullptr, st);
+    HIP_CHECK_RET(hipMemsetAsync(gout, 0, P_img * 4, st));
+    if (!T && ybar_in != O.yB)
+      HIP_CHECK_RET(hipMemcpyAsync(O.yB, ybar_in, (size_t)N * feat * 4, hipMemcpyDeviceToDevice, st));
+    launch_f32_to_act<AT>(T ? Q.CLSNB : O.CLSNB, T ? ybar_t_in : O.yB, (int64_t)N * D, st);
+    VIT_RC(mdd_op_layernorm_bwd(VDT, N, D, vit.eps, P.CLS, T ? Q.CLS : nullptr, O.CLSNB, T ? Q.CLSNB : nullptr,
+                                th + off_nw, tp(th_t + off_nw), nullptr, nullptr, T ? nullptr : O.CLSB,
+                                T ? Q.CLSB : nullptr, gp(off_nw), gt(off_nw), gp(off_nb), gt(off_nb), st));
+    launch_cls_scatter<AT>(T ? Q.XB[L_] : O.XB[L_], T ? Q.CLSB : O.CLSB, N, Tk, D, st);
+    for (int l = L_ - 1; l >= 0; --l) {
+      const VitBlkL& B = vblk[l]; VitActs& pa = P.vb[l]; VitActs& qa = Q.vb[l]; VitActs& oa = O.vb[l];
+      const AT *xb = O.XB[l + 1], *xb_t = Q.XB[l + 1];
+      // MLP branch
+      lin_bwd_w(T, convs[B.fc2], xb, xb_t, pa.A, qa.A, gout, st);
+      conv_bwd_d(T, convs[B.fc2], xb, xb_t, epi_lin(T ? qa.AB : oa.AB, nullptr), st);
+      VIT_RC(mdd_op_gelu_bwd(VDT, (int64_t)M * 4 * D, pa.C, T ? qa.C : nullptr, oa.AB, T ? qa.AB : nullptr,
+                             T ? nullptr : oa.CB, T ? qa.CB : nullptr, st));
+      lin_bwd_w(T, convs[B.fc1], oa.CB, qa.CB, pa.N2, qa.N2, gout, st);
+      conv_bwd_d(T, convs[B.fc1], oa.CB, qa.CB, epi_lin(T ? qa.N2B : oa.N2B, nullptr), st);
+      VIT_RC(mdd_op_layernorm_bwd(VDT, M, D, vit.eps, pa.X2, T ? qa.X2 : nullptr, oa.N2B, T ? qa.N2B : nullptr,
+                                  th + B.ln2_w, tp(th_t + B.ln2_w), xb, T ? xb_t : nullptr, T ? nullptr : oa.X2B,
+                                  T ? qa.X2B : nullptr, gp(B.ln2_w), gt(B.ln2_w), gp(B.ln2_b), gt(B.ln2_b), st));
+      // attention branch
+      lin_bwd_w(T, convs[B.proj], oa.X2B, qa.X2B, pa.O, qa.O, gout, st);
+      conv_bwd_d(T, convs[B.proj], oa.X2B, qa.X2B, epi_lin(T ? qa.OB : oa.OB, nullptr), st);
+      const AT *q = pa.QKV, *k = pa.QKV + D, *v = pa.QKV + 2 * D;
+      if (!T) {
+        AT* z = oa.QKVB;
+        VIT_RC(mdd_op_bgemm(VDT, 0, 1, &ad.dp, oa.OB, nullptr, v, nullptr, oa.PB, nullptr, st));
+        VIT_RC(mdd_op_softmax_bwd(rows, Tk, sld, scale, pa.P, nullptr, oa.PB, nullptr, oa.SB, nullptr, st));
+        VIT_RC(mdd_op_bgemm(VDT, 1, 0, &ad.dv, pa.P, nullptr, oa.OB, nullptr, z + 2 * D, nullptr, st));
+        VIT_RC(mdd_op_bgemm(VDT, 1, 0, &ad.dq, oa.SB, nullptr, k, nullptr, z, nullptr, st));
+        VIT_RC(mdd_op_bgemm(VDT, 1, 0, &ad.dk, oa.SB, nullptr, q, nullptr, z + D, nullptr, st));
+      } else {
+        const AT *q_t = qa.QKV, *k_t = qa.QKV + D, *v_t = qa.QKV + 2 * D;
+        AT* z = qa.QKVB;
+        VIT_RC(mdd_op_bgemm(VDT, 0, 1, &ad.dp, oa.OB, qa.OB, v, v_t, nullptr, qa.PB, st));
+        VIT_RC(mdd_op_softmax_bwd(rows, Tk, sld, scale, pa.P, qa.P, oa.PB, qa.PB, nullptr, qa.SB, st));
+        VIT_RC(mdd_op_bgemm(VDT, 1, 0, &ad.dv, pa.P, qa.P, oa.OB, qa.OB, nullptr, z + 2 * D, st));
+        VIT_RC(mdd_op_bgemm(VDT, 1, 0, &ad.dq, oa.SB, qa.SB, k, k_t, nullptr, z, st));
+        VIT_RC(mdd_op_bgemm(VDT, 1, 0, &ad.dk, oa.SB, qa.SB, q, q_t, nullptr, z + D, st));
+      }
+      lin_bwd_w(T, convs[B.qkv], oa.QKVB, qa.QKVB, pa.N1, qa.N1, gout, st);
+      conv_bwd_d(T, convs[B.qkv], oa.QKVB, qa.QKVB, epi_lin(T ? qa.N1B : oa.N1B, nullptr), st);
+      VIT_RC(mdd_op_layernorm_bwd(VDT, M, D, vit.eps, P.X[l], T ? Q.X[l] : nullptr, oa.N1B, T ? qa.N1B : nullptr,
+                                  th + B.ln1_w, tp(th_t + B.ln1_w), oa.X2B, T ? qa.X2B : nullptr,
+                                  T ? nullptr : O.XB[l], T ? Q.XB[l] : nullptr, gp(B.ln1_w), gt(B.ln1_w),
+                                  gp(B.ln1_b), gt(B.ln1_b), st));
+      flush_w(st);
+    }
+    launch_vit_embed_bwd<AT>(O.XB[0], T ? Q.XB[0] : nullptr, T ? nullptr : O.VPEB, T ? Q.VPEB : nullptr,
+                             gout + off_cls, gout + off_pos, N, Tk, D, st);
+    lin_bwd_w(T, convs[pe_conv], O.VPEB, Q.VPEB, P.VCOL, nullptr, gout, st);
+    if (dimage) {
+      AT* cb = T ? Q.VCOLB : O.VCOLB;
+      conv_bwd_d(T, convs[pe_conv], O.VPEB, Q.VPEB, epi_lin(cb, nullptr), st);
+      launch_unpatchify_accum<AT>(dimage, cb, idx, coef, mul, N, S, vit.patch, st);
+    }
+    flush_w(st, MAIN_TAIL);
+    join(st);
+    POST_WALK("vit_backward");
+    return 0;
+  }
+#undef VIT_RC
+
   // ------------------------------------------------------------------ image encoder: F / T-fwd
   int img_forward(bool T, int slot, const float* th, const float* th_t, const float* image,
                   const int64_t* idx, float* feat_out, hipStream_t st) override {
     CHECK_ARG(base, "workspace not bound");
     DevGuard guard(device_id);
     CHECK_ARG(slot >= 0 && slot < nslots, "slot out of range");
+    if (is_vit) return vit_forward(T, slot, th, th_t, image, idx, feat_out, st);
     ActSet& P = sets[slot]; ActSet& Q = tn;
     int nb = (int)blks.size();
     launch_ws_forward<AT>(d_descs, (int)descs.size(), total_rows, total_tiles, th, T ? th_t : nullptr, wf, wt,
@@ -763,6 +1042,7 @@ struct Eng : mdd_engine {
     CHECK_ARG(base, "workspace not bound");
     DevGuard guard(device_id);
     CHECK_ARG(slot >= 0 && slot < nslots, "slot out of range");
+    if (is_vit) return vit_backward(T, slot, th, th_t, ybar_in, ybar_t_in, gout, dimage, idx, coef, mul, repack, stash, st);
     ActSet& P = sets[slot]; ActSet& Q = tn;
     ActSet& O = (!T && !stash) ? tn : P;  // where primal backward signals are written
     int nb = (int)blks.size();

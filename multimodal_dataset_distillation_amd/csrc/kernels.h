@@ -216,3 +216,19 @@ void launch_contrastive(const LossWork& w, float* loss, float* xbar, float* ybar
                         float* xbar_t, float* ybar_t, float* sbar_t, const float* x,
                         const float* y, const float* x_t, const float* y_t, const float* scale_ptr,
                         float scale_const, int n, int d, hipStream_t st);
+
+// ---------------------------------------------------------------- vit.hip (ViT topology, BASELINE configs[4])
+template <class AT> void launch_patchify(AT* cols, const float* image, const int64_t* idx, int n, int s, int patch, hipStream_t st);
+template <class AT> void launch_unpatchify_accum(float* dimage, const AT* colsbar, const int64_t* idx, const float* coef,
+                                                 float mul, int n, int s, int patch, hipStream_t st);
+template <class AT> void launch_vit_embed(AT* x0, AT* x0_t, const AT* pe, const AT* pe_t, const float* cls, const float* cls_t,
+                                          const float* pos, const float* pos_t, int n, int tok, int dim, hipStream_t st);
+template <class AT> void launch_vit_embed_bwd(const AT* xb, const AT* xb_t, AT* peb, AT* peb_t, float* dcls, float* dpos,
+                                              int n, int tok, int dim, hipStream_t st);
+template <class AT> void launch_add2(AT* o, AT* o_t, const AT* a, const AT* a_t, const AT* b, const AT* b_t, int64_t elems,
+                                     hipStream_t st);
+template <class AT> void launch_cls_gather(AT* out, const AT* x, int n, int tok, int dim, hipStream_t st);
+template <class AT> void launch_cls_scatter(AT* xb, const AT* in, int n, int tok, int dim, hipStream_t st);
+template <class AT> void launch_act_to_f32(float* o, const AT* a, int64_t n, hipStream_t st);
+template <class AT> void launch_f32_to_act(AT* o, const float* a, int64_t n, hipStream_t st);
+template <class AT> void launch_lin_pack(AT* wf, AT* wt, const float* w, int out, int in, hipStream_t st);

@@ -110,6 +110,7 @@ template <class S, class AT, int MAXC>
 __global__ __launch_bounds__(256) void k_ln_bwd(const AT* __restrict__ x, const AT* __restrict__ x_t,
                                                 const AT* __restrict__ dy, const AT* __restrict__ dy_t,
                                                 const float* __restrict__ g, const float* __restrict__ g_t,
+                                                const AT* __restrict__ res, const AT* __restrict__ res_t,
                                                 AT* __restrict__ dx, AT* __restrict__ dx_t, float* __restrict__ dg,
                                                 float* __restrict__ dg_t, float* __restrict__ db,
                                                 float* __restrict__ db_t, int rows, int dim, float eps,
@@ -174,6 +175,12 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const AT* __restrict__ x, const 
         S o[CE];
 #pragma unroll
         for (int e = 0; e < CE; ++e) o[e] = rstd * (d[i][e] - m1 - v[i][e] * m2);
+        if (res) {             // the gradient arriving over the residual connection around this LayerNorm's branch
+          S r[CE];
+          ldcS<S, AT>(res, res_t, (int64_t)row * cch + c, r);
+#pragma unroll
+          for (int e = 0; e < CE; ++e) o[e] = o[e] + r[e];
+        }
         stcS<S, AT>(dx, dx_t, (int64_t)row * cch + c, o);
       }
     }
@@ -360,6 +367,133 @@ __global__ __launch_bounds__(256) void k_bgemm(const BG p) {
     }
 }
 
+// ------------------------------------------------------------------ patches <-> image
+// cols[(n*np + py*g + px), c*P*P + dy*P + dx] = image[idx[n], c, py*P + dy, px*P + dx]  (the K order of a
+// Conv2d(3, D, P, stride P) weight flattened [D][3*P*P]): the patch embedding becomes a pointwise contraction
+template <class AT>
+__global__ void k_patchify(AT* __restrict__ cols, const float* __restrict__ image, const int64_t* __restrict__ idx,
+                           int n, int s, int patch) {
+  const int g = s / patch, kk = 3 * patch * patch;
+  const int64_t total = (int64_t)n * g * g * kk;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % kk);
+    const int64_t r = i / kk;
+    const int px = (int)(r % g), py = (int)((r / g) % g), ni = (int)(r / ((int64_t)g * g));
+    const int dx = k % patch, dy = (k / patch) % patch, c = k / (patch * patch);
+    const int64_t src_n = idx ? idx[ni] : ni;
+    cols[i] = from_f<AT>(image[((src_n * 3 + c) * s + py * patch + dy) * (int64_t)s + px * patch + dx]);
+  }
+}
+// dimage[idx[n], c, y, x] += coef*mul * colsbar[...]   (patches do not overlap: every pixel is written by one thread)
+template <class AT>
+__global__ void k_unpatchify_accum(float* __restrict__ dimage, const AT* __restrict__ colsbar,
+                                   const int64_t* __restrict__ idx, const float* __restrict__ coef, float mul, int n,
+                                   int s, int patch) {
+  const int g = s / patch, kk = 3 * patch * patch;
+  const float a = mul * (coef ? coef[0] : 1.f);
+  const int64_t total = (int64_t)n * g * g * kk;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % kk);
+    const int64_t r = i / kk;
+    const int px = (int)(r % g), py = (int)((r / g) % g), ni = (int)(r / ((int64_t)g * g));
+    const int dx = k % patch, dy = (k / patch) % patch, c = k / (patch * patch);
+    const int64_t dst_n = idx ? idx[ni] : ni;
+    dimage[((dst_n * 3 + c) * s + py * patch + dy) * (int64_t)s + px * patch + dx] += a * to_f(colsbar[i]);
+  }
+}
+
+// ------------------------------------------------------------------ token assembly: x0[n, 0] = cls + pos[0], x0[n, 1+p] = pe[n, p] + pos[1+p]
+template <class S, class AT>
+__global__ void k_vit_embed(AT* __restrict__ x0, AT* __restrict__ x0_t, const AT* __restrict__ pe,
+                            const AT* __restrict__ pe_t, const float* __restrict__ cls, const float* __restrict__ cls_t,
+                            const float* __restrict__ pos, const float* __restrict__ pos_t, int n, int tok, int dim) {
+  const int64_t total = (int64_t)n * tok * dim;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % dim);
+    const int t = (int)((i / dim) % tok);
+    const int ni = (int)(i / ((int64_t)dim * tok));
+    S v = ldS<S>(pos, pos_t, (size_t)t * dim + d);
+    if (t == 0) v = v + ldS<S>(cls, cls_t, (size_t)d);
+    else v = v + ldS<S>(pe, pe_t, (size_t)(((int64_t)ni * (tok - 1) + t - 1) * dim + d));
+    stS<S>(x0, x0_t, (size_t)i, v);
+  }
+}
+// dpos[t] = sum_n xb[n, t] ; dcls = sum_n xb[n, 0] ; peb[n, p] = xb[n, 1+p].   One block per token position;
+// OVERWRITES its slices of the flat gradient (Dual: the tangent sums into the tangent gradient).
+template <class S, class AT>
+__global__ void k_vit_embed_bwd(const AT* __restrict__ xb, const AT* __restrict__ xb_t, AT* __restrict__ peb,
+                                AT* __restrict__ peb_t, float* __restrict__ dcls, float* __restrict__ dpos, int n,
+                                int tok, int dim) {
+  const int t = blockIdx.x;
+  for (int d = threadIdx.x; d < dim; d += blockDim.x) {
+    S acc = mk<S>(0.f, 0.f);
+    for (int ni = 0; ni < n; ++ni) {
+      const size_t src = (size_t)(((int64_t)ni * tok + t) * dim + d);
+      const S v = ldS<S>(xb, xb_t, src);
+      acc = acc + v;
+      if (t > 0) stS<S>(peb, peb_t, (size_t)(((int64_t)ni * (tok - 1) + t - 1) * dim + d), v);
+    }
+    const float r = IsDual<S>::v ? tan_(acc) : val(acc);
+    dpos[(size_t)t * dim + d] = r;
+    if (t == 0) dcls[d] = r;
+  }
+}
+
+// ------------------------------------------------------------------ small elementwise helpers
+template <class S, class AT>
+__global__ void k_add2(AT* __restrict__ o, AT* __restrict__ o_t, const AT* __restrict__ a, const AT* __restrict__ a_t,
+                       const AT* __restrict__ b, const AT* __restrict__ b_t, int64_t chunks) {
+  constexpr int CE = Chunk<AT>::N;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < chunks; i += (int64_t)gridDim.x * blockDim.x) {
+    S x[CE], y[CE];
+    ldcS<S, AT>(a, a_t, i, x);
+    ldcS<S, AT>(b, b_t, i, y);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) x[e] = x[e] + y[e];
+    stcS<S, AT>(o, o_t, i, x);
+  }
+}
+// rows (n, 0) of a [n, tok, dim] activation tensor <-> a dense [n, dim] one; fp32 <-> activation type
+template <class AT>
+__global__ void k_cls_gather(AT* __restrict__ out, const AT* __restrict__ x, int n, int tok, int dim) {
+  const int64_t total = (int64_t)n * dim;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = x[(i / dim) * (int64_t)tok * dim + (i % dim)];
+}
+template <class AT>
+__global__ void k_cls_scatter(AT* __restrict__ xb, const AT* __restrict__ in, int n, int tok, int dim) {
+  const int64_t total = (int64_t)n * tok * dim;      // every row of xb is written: zero except the class rows
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)((i / dim) % tok);
+    xb[i] = t == 0 ? in[(i / ((int64_t)tok * dim)) * dim + (i % dim)] : from_f<AT>(0.f);
+  }
+}
+template <class AT> __global__ void k_act_to_f32(float* __restrict__ o, const AT* __restrict__ a, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) o[i] = to_f(a[i]);
+}
+template <class AT> __global__ void k_f32_to_act(AT* __restrict__ o, const float* __restrict__ a, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) o[i] = from_f<AT>(a[i]);
+}
+// packed operands of a linear W [out][in] (fp32 in theta): wf = W as stored (B operand of the forward contraction),
+// wt = W^T [in][out] (B operand of the data gradient); 32x32 tiles through LDS
+template <class AT>
+__global__ void k_lin_pack(AT* __restrict__ wf, AT* __restrict__ wt, const float* __restrict__ w, int out, int in) {
+  __shared__ float tile[32][33];
+  const int i0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 256 threads: 8 rows per pass
+  for (int r = ty; r < 32; r += 8) {
+    const int o = o0 + r, i = i0 + tx;
+    float v = 0.f;
+    if (o < out && i < in) { v = w[(int64_t)o * in + i]; wf[(int64_t)o * in + i] = from_f<AT>(v); }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int i = i0 + r, o = o0 + tx;
+    if (o < out && i < in) wt[(int64_t)i * out + o] = from_f<AT>(tile[tx][r]);
+  }
+}
+
 inline int vgrid(int64_t items, int block = 256) {
   int64_t g = (items + block - 1) / block;
   return (int)std::max<int64_t>(1, std::min<int64_t>(g, 8192));
@@ -383,18 +517,19 @@ int ln_fwd(int rows, int dim, float eps, const void* x, const void* x_t, const f
 }
 template <class AT>
 int ln_bwd(int rows, int dim, float eps, const void* x, const void* x_t, const void* dy, const void* dy_t,
-           const float* g, const float* g_t, void* dx, void* dx_t, float* dg, float* dg_t, float* db, float* db_t,
-           hipStream_t st) {
+           const float* g, const float* g_t, const void* res, const void* res_t, void* dx, void* dx_t, float* dg,
+           float* dg_t, float* db, float* db_t, hipStream_t st) {
   const int cch = dim / Chunk<AT>::N, maxc = (cch + 63) / 64;
   const int rpb = 64, grid = (rows + rpb - 1) / rpb;
 #define LN_B(MC)                                                                                                 \
   do {                                                                                                           \
     if (x_t) k_ln_bwd<Dual, AT, MC><<<grid, 256, 0, st>>>((const AT*)x, (const AT*)x_t, (const AT*)dy,            \
-                                                          (const AT*)dy_t, g, g_t, (AT*)dx, (AT*)dx_t, dg, dg_t,  \
+                                                          (const AT*)dy_t, g, g_t, (const AT*)res,               \
+                                                          (const AT*)res_t, (AT*)dx, (AT*)dx_t, dg, dg_t,        \
                                                           db, db_t, rows, dim, eps, rpb);                        \
     else k_ln_bwd<float, AT, MC><<<grid, 256, 0, st>>>((const AT*)x, nullptr, (const AT*)dy, nullptr, g, nullptr, \
-                                                       (AT*)dx, nullptr, dg, nullptr, db, nullptr, rows, dim,    \
-                                                       eps, rpb);                                                \
+                                                       (const AT*)res, nullptr, (AT*)dx, nullptr, dg, nullptr,   \
+                                                       db, nullptr, rows, dim, eps, rpb);                        \
   } while (0)
   if (maxc == 1) LN_B(1); else if (maxc == 2) LN_B(2); else LN_B(3);
 #undef LN_B
@@ -410,6 +545,66 @@ void bgemm_types(const BG& p, int a_is_f32, int c_is_f32, dim3 grid, hipStream_t
 }
 
 }  // namespace
+
+template <class AT>
+void launch_patchify(AT* cols, const float* image, const int64_t* idx, int n, int s, int patch, hipStream_t st) {
+  k_patchify<AT><<<vgrid((int64_t)n * s * s * 3), 256, 0, st>>>(cols, image, idx, n, s, patch);
+}
+template <class AT>
+void launch_unpatchify_accum(float* dimage, const AT* colsbar, const int64_t* idx, const float* coef, float mul,
+                             int n, int s, int patch, hipStream_t st) {
+  k_unpatchify_accum<AT><<<vgrid((int64_t)n * s * s * 3), 256, 0, st>>>(dimage, colsbar, idx, coef, mul, n, s, patch);
+}
+template <class AT>
+void launch_vit_embed(AT* x0, AT* x0_t, const AT* pe, const AT* pe_t, const float* cls, const float* cls_t,
+                      const float* pos, const float* pos_t, int n, int tok, int dim, hipStream_t st) {
+  const int g = vgrid((int64_t)n * tok * dim);
+  if (x0_t) k_vit_embed<Dual, AT><<<g, 256, 0, st>>>(x0, x0_t, pe, pe_t, cls, cls_t, pos, pos_t, n, tok, dim);
+  else k_vit_embed<float, AT><<<g, 256, 0, st>>>(x0, nullptr, pe, nullptr, cls, nullptr, pos, nullptr, n, tok, dim);
+}
+template <class AT>
+void launch_vit_embed_bwd(const AT* xb, const AT* xb_t, AT* peb, AT* peb_t, float* dcls, float* dpos, int n, int tok,
+                          int dim, hipStream_t st) {
+  if (xb_t) k_vit_embed_bwd<Dual, AT><<<tok, 256, 0, st>>>(xb, xb_t, peb, peb_t, dcls, dpos, n, tok, dim);
+  else k_vit_embed_bwd<float, AT><<<tok, 256, 0, st>>>(xb, nullptr, peb, nullptr, dcls, dpos, n, tok, dim);
+}
+template <class AT>
+void launch_add2(AT* o, AT* o_t, const AT* a, const AT* a_t, const AT* b, const AT* b_t, int64_t elems, hipStream_t st) {
+  const int64_t ch = elems / Chunk<AT>::N;
+  if (o_t) k_add2<Dual, AT><<<vgrid(ch), 256, 0, st>>>(o, o_t, a, a_t, b, b_t, ch);
+  else k_add2<float, AT><<<vgrid(ch), 256, 0, st>>>(o, nullptr, a, nullptr, b, nullptr, ch);
+}
+template <class AT> void launch_cls_gather(AT* out, const AT* x, int n, int tok, int dim, hipStream_t st) {
+  k_cls_gather<AT><<<vgrid((int64_t)n * dim), 256, 0, st>>>(out, x, n, tok, dim);
+}
+template <class AT> void launch_cls_scatter(AT* xb, const AT* in, int n, int tok, int dim, hipStream_t st) {
+  k_cls_scatter<AT><<<vgrid((int64_t)n * tok * dim), 256, 0, st>>>(xb, in, n, tok, dim);
+}
+template <class AT> void launch_act_to_f32(float* o, const AT* a, int64_t n, hipStream_t st) {
+  k_act_to_f32<AT><<<vgrid(n), 256, 0, st>>>(o, a, n);
+}
+template <class AT> void launch_f32_to_act(AT* o, const float* a, int64_t n, hipStream_t st) {
+  k_f32_to_act<AT><<<vgrid(n), 256, 0, st>>>(o, a, n);
+}
+template <class AT> void launch_lin_pack(AT* wf, AT* wt, const float* w, int out, int in, hipStream_t st) {
+  k_lin_pack<AT><<<dim3((in + 31) / 32, (out + 31) / 32), 256, 0, st>>>(wf, wt, w, out, in);
+}
+#define VIT_INST(AT)                                                                                              \
+  template void launch_patchify<AT>(AT*, const float*, const int64_t*, int, int, int, hipStream_t);               \
+  template void launch_unpatchify_accum<AT>(float*, const AT*, const int64_t*, const float*, float, int, int, int, \
+                                            hipStream_t);                                                         \
+  template void launch_vit_embed<AT>(AT*, AT*, const AT*, const AT*, const float*, const float*, const float*,     \
+                                     const float*, int, int, int, hipStream_t);                                   \
+  template void launch_vit_embed_bwd<AT>(const AT*, const AT*, AT*, AT*, float*, float*, int, int, int, hipStream_t); \
+  template void launch_add2<AT>(AT*, AT*, const AT*, const AT*, const AT*, const AT*, int64_t, hipStream_t);       \
+  template void launch_cls_gather<AT>(AT*, const AT*, int, int, int, hipStream_t);                                \
+  template void launch_cls_scatter<AT>(AT*, const AT*, int, int, int, hipStream_t);                               \
+  template void launch_act_to_f32<AT>(float*, const AT*, int64_t, hipStream_t);                                   \
+  template void launch_f32_to_act<AT>(AT*, const float*, int64_t, hipStream_t);                                   \
+  template void launch_lin_pack<AT>(AT*, AT*, const float*, int, int, hipStream_t);
+VIT_INST(float)
+VIT_INST(bf16)
+#undef VIT_INST
 
 extern "C" {
 
@@ -429,18 +624,20 @@ int mdd_op_layernorm(int dtype, int rows, int dim, float eps, const void* x, con
 }
 
 int mdd_op_layernorm_bwd(int dtype, int rows, int dim, float eps, const void* x, const void* x_t, const void* dy,
-                         const void* dy_t, const float* gamma, const float* gamma_t, void* dx, void* dx_t,
-                         float* dgamma, float* dgamma_t, float* dbeta, float* dbeta_t, void* stream) {
+                         const void* dy_t, const float* gamma, const float* gamma_t, const void* res,
+                         const void* res_t, void* dx, void* dx_t, float* dgamma, float* dgamma_t, float* dbeta,
+                         float* dbeta_t, void* stream) {
   CHECK_ARG(rows > 0 && dim > 0 && x && dy && gamma, "null pointer / empty problem");
   const bool T = x_t != nullptr;
   CHECK_ARG(T == (dy_t != nullptr) && T == (gamma_t != nullptr) && T == (dx_t != nullptr) &&
                 T == (dgamma_t != nullptr) && T == (dbeta_t != nullptr), "tangent operands come together");
+  CHECK_ARG(!res || !T || res_t, "the residual gradient needs its tangent in a tangent call");
   CHECK_ARG(T || (dx && dgamma && dbeta), "output is null");
   CHECK_ARG(dtype == MDD_DTYPE_F32 || dtype == MDD_DTYPE_BF16, "dtype");
   const int ce = dtype == MDD_DTYPE_F32 ? 4 : 8;
   CHECK_ARG(dim % ce == 0 && dim / ce <= 192, "dim must be a multiple of the 16-byte chunk and at most 192 chunks");
-  if (dtype == MDD_DTYPE_F32) ln_bwd<float>(rows, dim, eps, x, x_t, dy, dy_t, gamma, gamma_t, dx, dx_t, dgamma, dgamma_t, dbeta, dbeta_t, (hipStream_t)stream);
-  else ln_bwd<bf16>(rows, dim, eps, x, x_t, dy, dy_t, gamma, gamma_t, dx, dx_t, dgamma, dgamma_t, dbeta, dbeta_t, (hipStream_t)stream);
+  if (dtype == MDD_DTYPE_F32) ln_bwd<float>(rows, dim, eps, x, x_t, dy, dy_t, gamma, gamma_t, res, res_t, dx, dx_t, dgamma, dgamma_t, dbeta, dbeta_t, (hipStream_t)stream);
+  else ln_bwd<bf16>(rows, dim, eps, x, x_t, dy, dy_t, gamma, gamma_t, res, res_t, dx, dx_t, dgamma, dgamma_t, dbeta, dbeta_t, (hipStream_t)stream);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

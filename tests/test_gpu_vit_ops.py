@@ -67,11 +67,19 @@ def test_layernorm_forward_backward_and_tangents(dtype, rows, dim, report):
     mod.check(lib.mdd_op_layernorm(DT[dtype], rows, dim, eps, P(xd), P(xtd), P(gd), P(gtd), P(bd), P(btd), P(y), P(yt), st))
     dx, dxt = torch.empty_like(xd), torch.empty_like(xd)
     dg, dgt, db, dbt = (torch.zeros(dim, device=DEV) for _ in range(4))
-    mod.check(lib.mdd_op_layernorm_bwd(DT[dtype], rows, dim, eps, P(xd), None, P(dyd), None, P(gd), None, P(dx), None,
-                                       P(dg), None, P(db), None, st))
-    mod.check(lib.mdd_op_layernorm_bwd(DT[dtype], rows, dim, eps, P(xd), P(xtd), P(dyd), P(dytd), P(gd), P(gtd), P(dx), P(dxt),
-                                       P(dg), P(dgt), P(db), P(dbt), st))
+    mod.check(lib.mdd_op_layernorm_bwd(DT[dtype], rows, dim, eps, P(xd), None, P(dyd), None, P(gd), None, None, None,
+                                       P(dx), None, P(dg), None, P(db), None, st))
+    mod.check(lib.mdd_op_layernorm_bwd(DT[dtype], rows, dim, eps, P(xd), P(xtd), P(dyd), P(dytd), P(gd), P(gtd), None, None,
+                                       P(dx), P(dxt), P(dg), P(dgt), P(db), P(dbt), st))
+    # with the gradient of the residual connection folded in (as the engine calls it): dx + res
+    dxr, dxrt = torch.empty_like(xd), torch.empty_like(xd)
+    scratch = [torch.zeros(dim, device=DEV) for _ in range(4)]
+    mod.check(lib.mdd_op_layernorm_bwd(DT[dtype], rows, dim, eps, P(xd), None, P(dyd), None, P(gd), None, P(dyd), None,
+                                       P(dxr), None, P(scratch[0]), None, P(scratch[1]), None, st))
+    mod.check(lib.mdd_op_layernorm_bwd(DT[dtype], rows, dim, eps, P(xd), P(xtd), P(dyd), P(dytd), P(gd), P(gtd), P(dyd), P(dytd),
+                                       P(dxr), P(dxrt), P(scratch[0]), P(scratch[2]), P(scratch[1]), P(scratch[3]), st))
     torch.cuda.synchronize()
+    assert rel_err(back(dxr), dx_ref + dy) < TOL[dtype] and rel_err(back(dxrt), dxt_ref + dyt) < TOL[dtype]
     e = dict(y=rel_err(back(y), y_ref), y_t=rel_err(back(yt), yt_ref), dx=rel_err(back(dx), dx_ref),
              dgamma=rel_err(back(dg), dg_ref), dbeta=rel_err(back(db), db_ref), dx_t=rel_err(back(dxt), dxt_ref),
              dgamma_t=rel_err(back(dgt), dgt_ref), dbeta_t=rel_err(back(dbt), dbt_ref))
