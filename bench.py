@@ -31,6 +31,7 @@ WORKLOADS = {
     "c2": ("nfnet_l0", 100, 8, 224, 768),     # BASELINE.json configs[1] -- the metric's config
     "c1": ("nfnet_l0", 10, 2, 224, 768),      # configs[0] (reference's CPU-runnable case)
     "c4": ("nfnet_l1", 500, 16, 224, 768),    # configs[3] per GPU (mode A); needs --keep-steps 0|1 to fit 288 GB
+    "c5": ("vit_b16", 100, 8, 224, 512),      # configs[4] per GPU: ViT-B/16 image encoder + 512-d CLIP text embeddings
     "tiny": ("nfnet_tiny", 4, 2, 64, 32),     # plumbing
 }
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md)
@@ -45,8 +46,13 @@ SELFCHECK_BUDGET = {"bf16": dict(grand=5e-3, g_img=1e-1, g_txt=9e-2, g_lr=2e-2),
                     "f32": dict(grand=1e-5, g_img=1e-4, g_txt=1e-4, g_lr=1e-4)}
 
 
-def algorithmic_flops_per_iter(n, syn_steps):
+def algorithmic_flops_per_iter(n, syn_steps, variant="nfnet_l0"):
     """9 contractions of forward size per conv/linear per step."""
+    if variant == "vit_b16":
+        T, D, L = 197, 768, 12     # per image: patch embedding + L x (qkv, proj, fc1, fc2, q k^T, p v) + 512->768 head
+        img = 196 * D * D + L * (T * (3 * D * D + D * D + 8 * D * D) + 2 * T * T * D)
+        macs_fwd = n * (img + 512 * D + D * D) + n * n * D
+        return syn_steps * 9 * 2 * macs_fwd
     macs_fwd = n * (4.2419e9 + 7.08e6) + n * n * 2304
     return syn_steps * 9 * 2 * macs_fwd
 
@@ -59,10 +65,15 @@ def cpu_baseline(workload, seconds_budget=30.0):
     and is labelled as an extrapolation."""
     from oracle import distill_ref as dr, nfnet_ref as nr
     variant, n, K, size, d_txt = WORKLOADS[workload]
-    sn, sK = (min(n, 10), min(K, 2)) if variant == "nfnet_l0" else (n, K)
+    sn, sK = (min(n, 10), min(K, 2)) if variant in ("nfnet_l0", "vit_b16") else (n, K)
     torch.manual_seed(0)
-    enc = nr.ImageEncoder(variant)
-    nr.randomize_like_trained(enc, 1)
+    if variant.startswith("vit"):
+        from oracle import vit_ref as vr
+        enc = vr.ImageEncoder(variant)
+        vr.randomize_like_trained(enc, 1)
+    else:
+        enc = nr.ImageEncoder(variant)
+        nr.randomize_like_trained(enc, 1)
     fi = dr.FlatModule(enc)
     ft = dr.FlatModule(dr.ProjectionHead(d_txt, enc.model.num_features))
     img, txt = dr.synthetic_inputs(sn, size, d_txt, seed=3)
@@ -156,8 +167,8 @@ def main():
     eng = UnrollEngine(variant, batch=n, num_queries=n, image_size=size, d_txt=d_txt, syn_steps=K,
                        dtype=args.dtype, device=dev, keep_steps=args.keep_steps)
     lib = _lib.load()
-    fd_check = args.workload == "c4" and not args.no_selfcheck
-    if args.workload == "c4":
+    fd_check = args.workload in ("c4", "c5") and not args.no_selfcheck
+    if args.workload in ("c4", "c5"):
         args.no_selfcheck = True     # an f32-mode engine of this size does not fit one GPU: the self-check is by
                                      # central differences of the reported loss instead (fd_check below)
 
@@ -253,7 +264,7 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * args.steps / dt
-        flops_iter = algorithmic_flops_per_iter(n, K) if variant == "nfnet_l0" else None
+        flops_iter = algorithmic_flops_per_iter(n, K, variant) if variant in ("nfnet_l0", "vit_b16") else None
         result = {
             "metric": "distillation iters/sec (%d syn pairs, syn_steps=%d)" % (n, K), "value": value,
             "unit": "iters/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -265,6 +276,9 @@ def main():
                        else ("BASELINE configs[3] per GPU: COCO-shaped, %d synthetic pairs, syn_steps=%d, %s + text "
                              "projection, %dx%d images, activations recomputed per keep_steps"
                              % (n, K, variant, size, size)) if args.workload == "c4"
+                       else ("BASELINE configs[4] per GPU: %d synthetic pairs, syn_steps=%d, ViT-B/16 image encoder "
+                             "(%s) + text projection 512->768, %dx%d images" % (n, K, variant, size, size))
+                       if args.workload == "c5"
                        else args.workload,
                        "global_batch": n, "syn_steps": K,
                        "keep_steps": eng.keep_steps, "workspace_gib": eng.workspace_bytes / 2**30,

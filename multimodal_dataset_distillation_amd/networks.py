@@ -20,8 +20,11 @@ import torch.nn as nn
 from .engine import UnrollEngine
 from . import functional as Fn
 
+# reference networks.py:660-676 names -> engine topologies.  'vit' is timm's vit_tiny_patch16_224 there (:668);
+# 'vit_b16' is BASELINE configs[4]'s ViT-B/16 (build-defined: the reference's 'clip' is ViT-B/32 through the clip package)
 VARIANTS = {"nfnet": "nfnet_l0", "nfnet_l0": "nfnet_l0", "nfnet_l1": "nfnet_l1",
-            "nfnet_tiny": "nfnet_tiny"}
+            "nfnet_tiny": "nfnet_tiny", "vit": "vit_tiny16", "vit_tiny16": "vit_tiny16", "vit_b16": "vit_b16",
+            "vit_micro": "vit_micro"}
 
 _ENGINES = {}
 
@@ -67,6 +70,25 @@ def init_image_params(table, generator=None, trained_like=False):
     0).  trained_like=True perturbs gains/biases the way oracle/nfnet_ref.randomize_like_trained
     does (synthetic expert snapshots; default init zeroes most of the theta-gradient)."""
     out = []
+    if any(name == "model.cls_token" for name, _, _ in table):
+        # timm VisionTransformer init: trunc_normal(0.02) linear weights and position embedding, zero biases, unit
+        # LayerNorm gains, class token N(0, 1e-6); trained_like perturbs gains / biases / class token
+        for name, shape, _ in table:
+            if name.endswith("cls_token"):
+                t = (0.02 if trained_like else 1e-6) * torch.randn(shape, generator=generator)
+            elif name.endswith("pos_embed"):
+                t = 0.02 * torch.randn(shape, generator=generator)
+            elif "norm" in name and name.endswith(".weight"):
+                t = 1.0 + (0.1 * torch.randn(shape, generator=generator) if trained_like else 0.0) * torch.ones(shape)
+            elif name.endswith(".weight"):
+                fan_in = 1
+                for d in shape[1:]:
+                    fan_in *= int(d)
+                t = torch.randn(shape, generator=generator) * (1.0 / math.sqrt(fan_in) if "patch_embed" in name else 0.02)
+            else:
+                t = 0.02 * torch.randn(shape, generator=generator) if trained_like else torch.zeros(shape)
+            out.append(t)
+        return out
     for name, shape, _ in table:
         if name.endswith(".weight"):
             fan_in = int(shape[1] * shape[2] * shape[3])
@@ -89,7 +111,7 @@ class ImageEncoder(nn.Module):
         name = variant or getattr(args, "image_encoder", "nfnet")
         if name not in VARIANTS:
             raise NotImplementedError(
-                "MI355X engine implements the NFNet image encoders %s; got %r" % (sorted(VARIANTS), name))
+                "MI355X engine implements the image encoders %s; got %r" % (sorted(VARIANTS), name))
         self.model_name = name
         self.variant = VARIANTS[name]
         self.compute_dtype = dtype or getattr(args, "compute_dtype", "bf16")
