@@ -14,6 +14,9 @@
 
 #define CHECK_ARG(cond, msg) \
   do { if (!(cond)) return mdd_set_error_msg(2, "mdd: invalid argument: " msg); } while (0)
+#ifndef MDD_VIT_MFMA_ATTENTION
+#define MDD_VIT_MFMA_ATTENTION 1   // bf16 storage: attention contractions on v_mfma_f32_32x32x16_bf16 (0: the S-generic FMA kernel)
+#endif
 
 namespace {
 
@@ -494,6 +497,75 @@ __global__ void k_lin_pack(AT* __restrict__ wf, AT* __restrict__ wt, const float
   }
 }
 
+// ------------------------------------------------------------------ the same contraction on the matrix cores (bf16 storage)
+// 64 x 64 output tile, four waves of 32 x 32 (v_mfma_f32_32x32x16_bf16), K-step 32.  Operands are staged through LDS
+// as bf16 rows of K (fp32 operands -- probabilities, score gradients -- are rounded on the way in: this is the bf16
+// mode, whose every other contraction rounds its operands the same way).  A tangent call accumulates
+// A_t B + A B_t only (the primal product was written by the primal call).  The element strides are arbitrary, so the
+// global loads are scalar; the thread -> element map follows whichever index is contiguous in memory.
+template <bool DUAL, class TA, class TC>
+__global__ __launch_bounds__(256) void k_bgemm_mfma(const BG p) {
+  constexpr int BM = 64, BN = 64, BK = 32, PITCH = BK + 8;     // bf16 elements; 80-byte rows: conflict-free 16-byte reads
+  __shared__ __attribute__((aligned(16))) bf16 As[DUAL ? 2 : 1][BM][PITCH];
+  __shared__ __attribute__((aligned(16))) bf16 Bs[DUAL ? 2 : 1][BN][PITCH];
+  const int b = blockIdx.z, o = b / p.inner, q = b - o * p.inner;
+  const TA* A = (const TA*)p.A + o * p.ao + q * p.aq;
+  const TA* At = (DUAL && p.A_t) ? (const TA*)p.A_t + o * p.ao + q * p.aq : nullptr;
+  const bf16* B = (const bf16*)p.B + o * p.bo + q * p.bq;
+  const bf16* Bt = (DUAL && p.B_t) ? (const bf16*)p.B_t + o * p.bo + q * p.bq : nullptr;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const bool a_kfast = p.sak == 1, b_kfast = p.sbk == 1;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = 0; k0 < p.K; k0 += BK) {
+#pragma unroll
+    for (int i = 0; i < BM * BK / 256; ++i) {
+      const int t = tid + 256 * i;
+      const int kk = a_kfast ? (t & (BK - 1)) : (t >> 6), mm = a_kfast ? (t >> 5) : (t & (BM - 1));
+      const int gm = m0 + mm, gk = k0 + kk;
+      const bool ok = gm < p.M && gk < p.K;
+      const int64_t off = gm * p.sam + gk * p.sak;
+      As[0][mm][kk] = (bf16)(ok ? to_f(A[off]) : 0.f);
+      if constexpr (DUAL) As[1][mm][kk] = (bf16)((ok && At) ? to_f(At[off]) : 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < BN * BK / 256; ++i) {
+      const int t = tid + 256 * i;
+      const int kk = b_kfast ? (t & (BK - 1)) : (t >> 6), nn = b_kfast ? (t >> 5) : (t & (BN - 1));
+      const int gn = n0 + nn, gk = k0 + kk;
+      const bool ok = gn < p.N && gk < p.K;
+      const int64_t off = gk * p.sbk + gn * p.sbn;
+      Bs[0][nn][kk] = ok ? B[off] : (bf16)0.f;
+      if constexpr (DUAL) Bs[1][nn][kk] = (ok && Bt) ? Bt[off] : (bf16)0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int kc = ks * 16 + (lane >> 5) * 8;
+      const bf16x8 a = *(const bf16x8*)&As[0][wm * 32 + (lane & 31)][kc];
+      const bf16x8 bb = *(const bf16x8*)&Bs[0][wn * 32 + (lane & 31)][kc];
+      if constexpr (DUAL) {
+        const bf16x8 at = *(const bf16x8*)&As[1][wm * 32 + (lane & 31)][kc];
+        const bf16x8 bt = *(const bf16x8*)&Bs[1][wn * 32 + (lane & 31)][kc];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at, bb, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bt, acc, 0, 0, 0);
+      } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, acc, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  TC* C = (TC*)(DUAL ? p.C_t : p.C) + o * p.co + q * p.cq;
+  const int gn = n0 + wn * 32 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (gm < p.M && gn < p.N) C[gm * p.scm + gn * p.scn] = from_f<TC>(acc[r] * p.alpha);
+  }
+}
+
 inline int vgrid(int64_t items, int block = 256) {
   int64_t g = (items + block - 1) / block;
   return (int)std::max<int64_t>(1, std::min<int64_t>(g, 8192));
@@ -534,6 +606,14 @@ int ln_bwd(int rows, int dim, float eps, const void* x, const void* x_t, const v
   if (maxc == 1) LN_B(1); else if (maxc == 2) LN_B(2); else LN_B(3);
 #undef LN_B
   return 0;
+}
+// bf16 storage: the matrix-core kernel for the two operand-type patterns attention uses
+template <bool DUAL>
+bool bgemm_mfma(const BG& p, int a_is_f32, int c_is_f32, dim3 grid, hipStream_t st) {
+  if (!a_is_f32 && c_is_f32) k_bgemm_mfma<DUAL, bf16, float><<<grid, 256, 0, st>>>(p);
+  else if (a_is_f32 && !c_is_f32) k_bgemm_mfma<DUAL, float, bf16><<<grid, 256, 0, st>>>(p);
+  else return false;
+  return true;
 }
 template <class S, class AT>
 void bgemm_types(const BG& p, int a_is_f32, int c_is_f32, dim3 grid, hipStream_t st) {
@@ -725,8 +805,12 @@ int mdd_op_bgemm(int dtype, int a_is_f32, int c_is_f32, const mdd_bgemm_desc* d,
     if (T) k_bgemm<Dual, float, float, float><<<grid, 256, 0, st>>>(p);
     else k_bgemm<float, float, float, float><<<grid, 256, 0, st>>>(p);
   } else {
-    if (T) bgemm_types<Dual, bf16>(p, a_is_f32, c_is_f32, grid, st);
-    else bgemm_types<float, bf16>(p, a_is_f32, c_is_f32, grid, st);
+    const bool done = MDD_VIT_MFMA_ATTENTION && (T ? bgemm_mfma<true>(p, a_is_f32, c_is_f32, grid, st)
+                                                     : bgemm_mfma<false>(p, a_is_f32, c_is_f32, grid, st));
+    if (!done) {
+      if (T) bgemm_types<Dual, bf16>(p, a_is_f32, c_is_f32, grid, st);
+      else bgemm_types<float, bf16>(p, a_is_f32, c_is_f32, grid, st);
+    }
   }
   HIP_CHECK_RET(hipGetLastError());
   return 0;
