@@ -8,6 +8,7 @@
 // Status: op-level entry points (include/mdd_hip.h `mdd_op_*`), parity-tested against torch; the engine topology
 // that walks them is the next step.
 #include <algorithm>
+#include <type_traits>
 
 #include "kernels.h"
 #include "mdd_hip.h"
@@ -515,30 +516,82 @@ __global__ __launch_bounds__(256) void k_bgemm_mfma(const BG p) {
   const bf16* Bt = (DUAL && p.B_t) ? (const bf16*)p.B_t + o * p.bo + q * p.bq : nullptr;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  // Staging: a thread fetches EIGHT consecutive elements along the index that is contiguous in memory with one or two
+  // 16-byte loads when that run is aligned and inside the matrix (callers' strides: heads are 64 wide, score rows are
+  // padded to a multiple of four floats), element by element otherwise.  vec_* are block-uniform.
+  constexpr int AE = 16 / (int)sizeof(TA);                        // elements per 16-byte load of A
   const bool a_kfast = p.sak == 1, b_kfast = p.sbk == 1;
+  const bool a_vec = (a_kfast ? (p.sam % AE == 0) : (p.sak % AE == 0 && p.sam == 1)) &&
+                     (((uintptr_t)A | (uintptr_t)(At ? At : A)) & 15) == 0;
+  const bool b_vec = (b_kfast ? (p.sbn % 8 == 0) : (p.sbk % 8 == 0 && p.sbn == 1)) &&
+                     (((uintptr_t)B | (uintptr_t)(Bt ? Bt : B)) & 15) == 0;
+  // run r of thread tid: (fixed index f, first running index g0) ; 64 x 32 tile = 256 runs of 8
+  const int a_f = a_kfast ? (tid >> 2) : (tid >> 3), a_g = a_kfast ? (tid & 3) * 8 : (tid & 7) * 8;   // kfast: f = m, g = k
+  const int b_f = b_kfast ? (tid >> 2) : (tid >> 3), b_g = b_kfast ? (tid & 3) * 8 : (tid & 7) * 8;   // else  f = k, g = m / n
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int k0 = 0; k0 < p.K; k0 += BK) {
+  auto fetch8 = [&](const auto* src, bool vec, int64_t off, int64_t step, int valid, float* out) {
+    using T = std::remove_cv_t<std::remove_pointer_t<decltype(src)>>;
+    constexpr int E = 16 / (int)sizeof(T);
+    if (vec && valid == 8) {
+      if constexpr (E == 8) {
+        float f[8];
+        Chunk<bf16>::unpack(*(const uint4*)(src + off), f);
 #pragma unroll
-    for (int i = 0; i < BM * BK / 256; ++i) {
-      const int t = tid + 256 * i;
-      const int kk = a_kfast ? (t & (BK - 1)) : (t >> 6), mm = a_kfast ? (t >> 5) : (t & (BM - 1));
-      const int gm = m0 + mm, gk = k0 + kk;
-      const bool ok = gm < p.M && gk < p.K;
-      const int64_t off = gm * p.sam + gk * p.sak;
-      As[0][mm][kk] = (bf16)(ok ? to_f(A[off]) : 0.f);
-      if constexpr (DUAL) As[1][mm][kk] = (bf16)((ok && At) ? to_f(At[off]) : 0.f);
+        for (int e = 0; e < 8; ++e) out[e] = f[e];
+      } else {
+        const float4 lo = *(const float4*)(src + off), hi = *(const float4*)(src + off + 4);
+        out[0] = lo.x; out[1] = lo.y; out[2] = lo.z; out[3] = lo.w; out[4] = hi.x; out[5] = hi.y; out[6] = hi.z; out[7] = hi.w;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) out[e] = e < valid ? to_f(src[off + e * step]) : 0.f;
     }
+  };
+  for (int k0 = 0; k0 < p.K; k0 += BK) {
+    {   // A tile -> As[m][k]
+      const int gm = a_kfast ? m0 + a_f : m0 + a_g, gk = a_kfast ? k0 + a_g : k0 + a_f;
+      const int lim = a_kfast ? p.K - gk : p.M - gm;                       // elements of the run that exist
+      const bool row_ok = a_kfast ? gm < p.M : gk < p.K;
+      const int valid = row_ok ? max(0, min(8, lim)) : 0;
+      const int64_t off = (int64_t)gm * p.sam + (int64_t)gk * p.sak, step = a_kfast ? 1 : p.sam;
+      float v[8], vt[8];
+      fetch8(A, a_vec, off, step, valid, v);
+      if constexpr (DUAL) { if (At) fetch8(At, a_vec, off, step, valid, vt); else { for (int e = 0; e < 8; ++e) vt[e] = 0.f; } }
+      if (a_kfast) {
+        float pk[8];
 #pragma unroll
-    for (int i = 0; i < BN * BK / 256; ++i) {
-      const int t = tid + 256 * i;
-      const int kk = b_kfast ? (t & (BK - 1)) : (t >> 6), nn = b_kfast ? (t >> 5) : (t & (BN - 1));
-      const int gn = n0 + nn, gk = k0 + kk;
-      const bool ok = gn < p.N && gk < p.K;
-      const int64_t off = gk * p.sbk + gn * p.sbn;
-      Bs[0][nn][kk] = ok ? B[off] : (bf16)0.f;
-      if constexpr (DUAL) Bs[1][nn][kk] = (ok && Bt) ? Bt[off] : (bf16)0.f;
+        for (int e = 0; e < 8; ++e) pk[e] = v[e];
+        *(uint4*)&As[0][a_f][a_g] = Chunk<bf16>::pack(pk);
+        if constexpr (DUAL) *(uint4*)&As[1][a_f][a_g] = Chunk<bf16>::pack(vt);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          As[0][a_g + e][a_f] = (bf16)v[e];
+          if constexpr (DUAL) As[1][a_g + e][a_f] = (bf16)vt[e];
+        }
+      }
+    }
+    {   // B tile -> Bs[n][k]
+      const int gn = b_kfast ? n0 + b_f : n0 + b_g, gk = b_kfast ? k0 + b_g : k0 + b_f;
+      const int lim = b_kfast ? p.K - gk : p.N - gn;
+      const bool row_ok = b_kfast ? gn < p.N : gk < p.K;
+      const int valid = row_ok ? max(0, min(8, lim)) : 0;
+      const int64_t off = (int64_t)gk * p.sbk + (int64_t)gn * p.sbn, step = b_kfast ? 1 : p.sbn;
+      float v[8], vt[8];
+      fetch8(B, b_vec, off, step, valid, v);
+      if constexpr (DUAL) { if (Bt) fetch8(Bt, b_vec, off, step, valid, vt); else { for (int e = 0; e < 8; ++e) vt[e] = 0.f; } }
+      if (b_kfast) {
+        *(uint4*)&Bs[0][b_f][b_g] = Chunk<bf16>::pack(v);
+        if constexpr (DUAL) *(uint4*)&Bs[1][b_f][b_g] = Chunk<bf16>::pack(vt);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          Bs[0][b_g + e][b_f] = (bf16)v[e];
+          if constexpr (DUAL) Bs[1][b_g + e][b_f] = (bf16)vt[e];
+        }
+      }
     }
     __syncthreads();
 #pragma unroll

@@ -117,3 +117,34 @@ def test_vit_outer_iteration_matches_the_oracle(variant, nq, batch, size, d_txt,
         assert float(e["grand"]) < tol_s and float(e["ces"]) < tol_s, e
         assert float(e["g_img"]) < tol_g and float(e["g_txt"]) < tol_g and float(e["g_lr"]) < tol_g, e
         eng.close()
+
+
+def test_vit_through_the_stage1_and_stage2_drivers(report, tmp_path):
+    """`--image_encoder vit_micro --text_encoder clip` (512-d text embeddings) through buffer.py -> files in the
+    reference's layout -> distill.py, the same route the NFNet encoders take (reference buffer.py:104-112,
+    distill.py:255-283, 509-613)."""
+    import os
+    from multimodal_dataset_distillation_amd import buffer, distill, networks as nw
+    bdir = str(tmp_path / "buffers")
+    args = buffer.build_parser().parse_args(
+        ["--dataset", "flickr", "--num_experts", "2", "--train_epochs", "3", "--batch_train", "4", "--image_size", "32",
+         "--image_encoder", "vit_micro", "--text_encoder", "clip", "--synthetic_data", "2", "--compute_dtype", "f32",
+         "--buffer_path", bdir])
+    buffer.main(args)
+    d = os.path.join(bdir, "flickr", "vit_micro", "clip")
+    assert sorted(os.listdir(d)) == ["img_replay_buffer_0.pt", "img_replay_buffer_1.pt", "txt_replay_buffer_0.pt",
+                                     "txt_replay_buffer_1.pt"]
+    traj = torch.load(os.path.join(d, "img_replay_buffer_0.pt"), map_location="cpu", weights_only=True)
+    assert len(traj[0]) == 4 and tuple(traj[0][0][0].shape) == (1, 1, 64)          # cls_token first, init + 3 epochs
+    moved = sum(float((a - b).abs().sum()) for a, b in zip(traj[0][0], traj[0][3]))
+    assert moved > 0
+    a, _ = distill.build_parser().parse_known_args(
+        ["--image_encoder", "vit_micro", "--text_encoder", "clip", "--num_queries", "4", "--mini_batch_size", "4",
+         "--syn_steps", "2", "--expert_epochs", "1", "--max_start_epoch", "2", "--Iteration", "3", "--image_size", "32",
+         "--lr_img", "0.5", "--lr_txt", "0.5", "--lr_lr", "1e-5", "--compute_dtype", "bf16x2", "--buffer_path", d,
+         "--max_files", "2"])
+    img, txt, lr = distill.main(a)
+    assert txt.shape == (4, 512)
+    assert torch.isfinite(img).all() and torch.isfinite(txt).all() and torch.isfinite(lr).all()
+    report(f"vit_micro: buffer.py -> 4 files -> distill.py: |image_syn| {img.norm().item():.3f} lr {lr.tolist()}")
+    nw.release_engines()
