@@ -117,6 +117,19 @@ def test_vit_outer_iteration_matches_the_oracle(variant, nq, batch, size, d_txt,
         assert float(e["grand"]) < tol_s and float(e["ces"]) < tol_s, e
         assert float(e["g_img"]) < tol_g and float(e["g_txt"]) < tol_g and float(e["g_lr"]) < tol_g, e
         eng.close()
+    # activation stash policy: every step recomputed in the reverse sweep must give the same iteration
+    eng = UnrollEngine(variant, batch=batch, num_queries=nq, image_size=size, d_txt=d_txt, syn_steps=K, dtype="f32",
+                       keep_steps=0)
+    lr = torch.tensor([0.1, 0.07], device=DEV)
+    out = eng.unrolled_match(case["img"].to(DEV), case["txt"].to(DEV), lr[0:1], lr[1:2], case["th0i"].to(DEV),
+                             case["th0t"].to(DEV), case["tgi"].to(DEV), case["tgt"].to(DEV), perms=case["perms"].to(DEV))
+    torch.cuda.synchronize()
+    w = case["want"]
+    e = dict(g_img=rel_err(out["image_syn"], w["g_img"]), g_txt=rel_err(out["text_syn"], w["g_txt"]),
+             g_lr=rel_err(out["lr"], w["g_lr"]))
+    report(f"{variant} outer iteration keep_steps=0 f32: " + " ".join(f"{k} {float(v):.2e}" for k, v in e.items()))
+    assert all(float(v) < 1e-5 for v in e.values()), e
+    eng.close()
 
 
 def test_vit_through_the_stage1_and_stage2_drivers(report, tmp_path):
