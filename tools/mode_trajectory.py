@@ -19,26 +19,26 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def train_experts(buffer_dir, experts, epochs, steps_per_epoch):
+def train_experts(buffer_dir, experts, epochs, steps_per_epoch, encoder="nfnet", text_encoder="bert"):
     """Stage 1 (buffer.py) on random pairs: real SGD trajectories of the student architecture, so that the expert's
     per-epoch move is commensurate with the student's syn_steps-step move and the matching loss is O(1)-sensitive
     to what stage 2 computes (random-walk snapshots with a fixed tiny step leave the normalised loss at 2.0)."""
     from multimodal_dataset_distillation_amd import buffer
     argv = ["--dataset", "flickr", "--num_experts", str(experts), "--train_epochs", str(epochs), "--batch_train", "128",
             "--synthetic_data", str(steps_per_epoch), "--buffer_path", buffer_dir, "--compute_dtype", "bf16x2",
-            "--image_encoder", "nfnet", "--seed", "0"]
+            "--image_encoder", encoder, "--text_encoder", text_encoder, "--seed", "0"]
     args, _ = buffer.build_parser().parse_known_args(argv)
     print("[mode_trajectory] stage 1: %d experts x %d epochs x %d steps" % (experts, epochs, steps_per_epoch),
           file=sys.stderr, flush=True)
     with contextlib.redirect_stdout(io.StringIO()):
         buffer.main(args)
-    return os.path.join(buffer_dir, "flickr", "nfnet", "bert")     # where the reference's stage 2 looks (distill.py:255)
+    return os.path.join(buffer_dir, "flickr", encoder, text_encoder)     # where the reference's stage 2 looks (distill.py:255)
 
 
-def run(dtype, iters, lrs, pairs, steps, buffer_dir):
+def run(dtype, iters, lrs, pairs, steps, buffer_dir, encoder="nfnet", text_encoder="bert"):
     import torch
     from multimodal_dataset_distillation_amd import distill
-    argv = ["--image_encoder", "nfnet", "--num_queries", str(pairs), "--mini_batch_size", str(pairs),
+    argv = ["--image_encoder", encoder, "--text_encoder", text_encoder, "--num_queries", str(pairs), "--mini_batch_size", str(pairs),
             "--syn_steps", str(steps), "--expert_epochs", "1", "--max_start_epoch", "2", "--dataset", "flickr",
             "--buffer_path", buffer_dir, "--max_files", "2", "--Iteration", str(iters), "--compute_dtype", dtype, "--seed", "0",
             "--lr_img", str(lrs[0]), "--lr_txt", str(lrs[1]), "--lr_lr", str(lrs[2]), "--eval_it", "1000000"]
@@ -64,17 +64,20 @@ def main():
     ap.add_argument("--lr_txt", type=float, default=1000.0)
     ap.add_argument("--lr_lr", type=float, default=1e-3)
     ap.add_argument("--experts", type=int, default=2)
+    ap.add_argument("--image_encoder", default="nfnet")
+    ap.add_argument("--text_encoder", default="bert")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     lrs = (a.lr_img, a.lr_txt, a.lr_lr)
     import tempfile
     bdir = tempfile.mkdtemp(prefix="mdd_experts_")
-    bdir = train_experts(bdir, a.experts, 3, a.syn_steps)
-    x0 = run("bf16", 0, (0.0, 0.0, 0.0), a.pairs, a.syn_steps, bdir)    # the seed's initial synthetic set (zero steps)
-    res = {m: run(m, a.iters, lrs, a.pairs, a.syn_steps, bdir) for m in ("f32", "bf16x2", "bf16")}
+    enc = (a.image_encoder, a.text_encoder)
+    bdir = train_experts(bdir, a.experts, 3, a.syn_steps, *enc)
+    x0 = run("bf16", 0, (0.0, 0.0, 0.0), a.pairs, a.syn_steps, bdir, *enc)    # the seed's initial synthetic set (zero steps)
+    res = {m: run(m, a.iters, lrs, a.pairs, a.syn_steps, bdir, *enc) for m in ("f32", "bf16x2", "bf16")}
     ref = res["f32"]
     rel = lambda u, v: float((u - v).norm() / (v.norm() + 1e-30))
-    out = {"config": {"pairs": a.pairs, "syn_steps": a.syn_steps, "outer_iterations": a.iters + 1, "lr": lrs},
+    out = {"config": {"image_encoder": a.image_encoder, "text_encoder": a.text_encoder, "pairs": a.pairs, "syn_steps": a.syn_steps, "outer_iterations": a.iters + 1, "lr": lrs},
            "moved_from_init_f32": {"image_syn": rel(ref[0], x0[0]) , "text_syn": rel(ref[1], x0[1]),
                                    "image_syn_abs": float((ref[0] - x0[0]).norm()), "text_syn_abs": float((ref[1] - x0[1]).norm())},
            "modes": {}}
