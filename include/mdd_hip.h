@@ -244,7 +244,9 @@ int mdd_allreduce_syn_grads(mdd_comm* c, float* buf_dev, int64_t n, int average,
  *   softmax        p = softmax(scale * s) over `cols` of each row (row stride ld); softmax_bwd  ds = scale*p*(dp - <p,dp>)
  *   bgemm          C[b] = alpha * A[b] B[b] for b = (o < outer, q < inner), every operand addressed by element strides
  *                  (transposes and the head slices of a fused qkv tensor need no copy).  bf16 dtype: a_is_f32 /
- *                  c_is_f32 say which of A, C are fp32 tensors (scores, probabilities); B is always activation-typed. */
+ *                  c_is_f32 say which of A, C are fp32 tensors (scores, probabilities); B is always activation-typed.
+ *                  dtype MDD_DTYPE_BF16X2: fp32 tensors throughout, every product as hi*hi + hi*lo + lo*hi of split-bf16
+ *                  operands on the matrix cores (the engine's bf16x2 mode); MDD_DTYPE_F32: exact fp32 FMA. */
 typedef struct mdd_bgemm_desc {
   int32_t m, n, k, outer, inner;
   int64_t a_row, a_col, b_row, b_col, c_row, c_col;               /* A(i,kk) = A[i*a_row + kk*a_col], B(kk,j) = B[kk*b_row + j*b_col] */

@@ -798,6 +798,8 @@ struct Eng : mdd_engine {
   // into the flat gradient (a linear's packed layout is its parameter layout); LayerNorm / GELU / softmax / the
   // attention contractions are the S-generic kernels of vit.hip (mdd_op_*), whose tangent calls write only `_t`.
   static constexpr int VDT = sizeof(AT) == 4 ? MDD_DTYPE_F32 : MDD_DTYPE_BF16;
+  // the attention contractions follow the engine's precision mode: exact FMA (f32), split-bf16 MFMA (bf16x2), bf16 MFMA
+  int bdt() const { return sizeof(AT) == 4 ? (prec == 1 ? MDD_DTYPE_BF16X2 : MDD_DTYPE_F32) : MDD_DTYPE_BF16; }
   void vit_pack(const float* th, const float* th_t, hipStream_t st) {
     for (auto& L : convs) {
       launch_lin_pack<AT>(wf + L.off_p, wt + L.off_p, th + L.off_w, L.cout, L.cin, st);
@@ -858,13 +860,13 @@ struct Eng : mdd_engine {
       const AT *q = pa.QKV, *k = pa.QKV + D, *v = pa.QKV + 2 * D;
       const AT *q_t = T ? qa.QKV : nullptr, *k_t = T ? qa.QKV + D : nullptr, *v_t = T ? qa.QKV + 2 * D : nullptr;
       if (!T) {
-        VIT_RC(mdd_op_bgemm(VDT, 0, 1, &ad.s, q, nullptr, k, nullptr, pa.P, nullptr, st));
+        VIT_RC(mdd_op_bgemm(bdt(), 0, 1, &ad.s, q, nullptr, k, nullptr, pa.P, nullptr, st));
         VIT_RC(mdd_op_softmax(rows, Tk, sld, scale, pa.P, nullptr, pa.P, nullptr, st));
-        VIT_RC(mdd_op_bgemm(VDT, 1, 0, &ad.o, pa.P, nullptr, v, nullptr, pa.O, nullptr, st));
+        VIT_RC(mdd_op_bgemm(bdt(), 1, 0, &ad.o, pa.P, nullptr, v, nullptr, pa.O, nullptr, st));
       } else {
-        VIT_RC(mdd_op_bgemm(VDT, 0, 1, &ad.s, q, q_t, k, k_t, nullptr, qa.P, st));
+        VIT_RC(mdd_op_bgemm(bdt(), 0, 1, &ad.s, q, q_t, k, k_t, nullptr, qa.P, st));
         VIT_RC(mdd_op_softmax_bwd(rows, Tk, sld, scale, pa.P, nullptr, qa.P, nullptr, qa.P, nullptr, st));
-        VIT_RC(mdd_op_bgemm(VDT, 1, 0, &ad.o, pa.P, qa.P, v, v_t, nullptr, qa.O, st));
+        VIT_RC(mdd_op_bgemm(bdt(), 1, 0, &ad.o, pa.P, qa.P, v, v_t, nullptr, qa.O, st));
       }
       conv_fwd(T, convs[B.proj], pa.O, qa.O, P.TMP, Q.TMP, nullptr, nullptr, 1.f, th, th_t, st);
       launch_add2<AT>(pa.X2, T ? qa.X2 : nullptr, x, x_t, P.TMP, T ? Q.TMP : nullptr, (int64_t)M * D, st);
@@ -931,19 +933,19 @@ struct Eng : mdd_engine {
       const AT *q = pa.QKV, *k = pa.QKV + D, *v = pa.QKV + 2 * D;
       if (!T) {
         AT* z = oa.QKVB;
-        VIT_RC(mdd_op_bgemm(VDT, 0, 1, &ad.dp, oa.OB, nullptr, v, nullptr, oa.PB, nullptr, st));
+        VIT_RC(mdd_op_bgemm(bdt(), 0, 1, &ad.dp, oa.OB, nullptr, v, nullptr, oa.PB, nullptr, st));
         VIT_RC(mdd_op_softmax_bwd(rows, Tk, sld, scale, pa.P, nullptr, oa.PB, nullptr, oa.SB, nullptr, st));
-        VIT_RC(mdd_op_bgemm(VDT, 1, 0, &ad.dv, pa.P, nullptr, oa.OB, nullptr, z + 2 * D, nullptr, st));
-        VIT_RC(mdd_op_bgemm(VDT, 1, 0, &ad.dq, oa.SB, nullptr, k, nullptr, z, nullptr, st));
-        VIT_RC(mdd_op_bgemm(VDT, 1, 0, &ad.dk, oa.SB, nullptr, q, nullptr, z + D, nullptr, st));
+        VIT_RC(mdd_op_bgemm(bdt(), 1, 0, &ad.dv, pa.P, nullptr, oa.OB, nullptr, z + 2 * D, nullptr, st));
+        VIT_RC(mdd_op_bgemm(bdt(), 1, 0, &ad.dq, oa.SB, nullptr, k, nullptr, z, nullptr, st));
+        VIT_RC(mdd_op_bgemm(bdt(), 1, 0, &ad.dk, oa.SB, nullptr, q, nullptr, z + D, nullptr, st));
       } else {
         const AT *q_t = qa.QKV, *k_t = qa.QKV + D, *v_t = qa.QKV + 2 * D;
         AT* z = qa.QKVB;
-        VIT_RC(mdd_op_bgemm(VDT, 0, 1, &ad.dp, oa.OB, qa.OB, v, v_t, nullptr, qa.PB, st));
+        VIT_RC(mdd_op_bgemm(bdt(), 0, 1, &ad.dp, oa.OB, qa.OB, v, v_t, nullptr, qa.PB, st));
         VIT_RC(mdd_op_softmax_bwd(rows, Tk, sld, scale, pa.P, qa.P, oa.PB, qa.PB, nullptr, qa.SB, st));
-        VIT_RC(mdd_op_bgemm(VDT, 1, 0, &ad.dv, pa.P, qa.P, oa.OB, qa.OB, nullptr, z + 2 * D, st));
-        VIT_RC(mdd_op_bgemm(VDT, 1, 0, &ad.dq, oa.SB, qa.SB, k, k_t, nullptr, z, st));
-        VIT_RC(mdd_op_bgemm(VDT, 1, 0, &ad.dk, oa.SB, qa.SB, q, q_t, nullptr, z + D, st));
+        VIT_RC(mdd_op_bgemm(bdt(), 1, 0, &ad.dv, pa.P, qa.P, oa.OB, qa.OB, nullptr, z + 2 * D, st));
+        VIT_RC(mdd_op_bgemm(bdt(), 1, 0, &ad.dq, oa.SB, qa.SB, k, k_t, nullptr, z, st));
+        VIT_RC(mdd_op_bgemm(bdt(), 1, 0, &ad.dk, oa.SB, qa.SB, q, q_t, nullptr, z + D, st));
       }
       lin_bwd_w(T, convs[B.qkv], oa.QKVB, qa.QKVB, pa.N1, qa.N1, gout, st);
       conv_bwd_d(T, convs[B.qkv], oa.QKVB, qa.QKVB, epi_lin(T ? qa.N1B : oa.N1B, nullptr), st);
