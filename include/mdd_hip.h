@@ -241,7 +241,9 @@ int mdd_allreduce_syn_grads(mdd_comm* c, float* buf_dev, int64_t n, int average,
  *   layernorm_bwd  dx (+ `res` when non-NULL: the gradient arriving over the residual connection), and dgamma / dbeta
  *                  ACCUMULATED (+=, fp32 atomics) into the caller's zeroed/partial sums
  *   gelu           a = GELU(c) (exact, erf);  gelu_bwd  cbar = abar * GELU'(c)
- *   softmax        p = softmax(scale * s) over `cols` of each row (row stride ld); softmax_bwd  ds = scale*p*(dp - <p,dp>)
+ *   softmax        p = softmax(scale * s) over `cols` of each row (row stride ld); softmax_bwd  ds = scale*p*(dp - <p,dp>);
+ *                  dtype = the storage type of the score tensors (the engine's bf16 mode keeps them in bf16: the matrix-core
+ *                  contractions round them to bf16 anyway)
  *   bgemm          C[b] = alpha * A[b] B[b] for b = (o < outer, q < inner), every operand addressed by element strides
  *                  (transposes and the head slices of a fused qkv tensor need no copy).  bf16 dtype: a_is_f32 /
  *                  c_is_f32 say which of A, C are fp32 tensors (scores, probabilities); B is always activation-typed.
@@ -262,10 +264,10 @@ int mdd_op_layernorm_bwd(int dtype, int rows, int dim, float eps, const void* x,
 int mdd_op_gelu(int dtype, int64_t n, const void* c, const void* c_t, void* a, void* a_t, void* stream);
 int mdd_op_gelu_bwd(int dtype, int64_t n, const void* c, const void* c_t, const void* abar, const void* abar_t,
                     void* cbar, void* cbar_t, void* stream);
-int mdd_op_softmax(int64_t rows, int cols, int ld, float scale, const float* s, const float* s_t, float* p,
-                   float* p_t, void* stream);
-int mdd_op_softmax_bwd(int64_t rows, int cols, int ld, float scale, const float* p, const float* p_t,
-                       const float* dp, const float* dp_t, float* ds, float* ds_t, void* stream);
+int mdd_op_softmax(int dtype, int64_t rows, int cols, int ld, float scale, const void* s, const void* s_t, void* p,
+                   void* p_t, void* stream);
+int mdd_op_softmax_bwd(int dtype, int64_t rows, int cols, int ld, float scale, const void* p, const void* p_t,
+                       const void* dp, const void* dp_t, void* ds, void* ds_t, void* stream);
 int mdd_op_bgemm(int dtype, int a_is_f32, int c_is_f32, const mdd_bgemm_desc* d, const void* A, const void* A_t,
                  const void* B, const void* B_t, void* C, void* C_t, void* stream);
 

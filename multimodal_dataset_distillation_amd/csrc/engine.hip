@@ -194,9 +194,9 @@ struct Eng : mdd_engine {
   };
   struct VitActs {
     AT *N1, *QKV, *O, *X2, *N2, *C, *A;       // LayerNorm 1, fused qkv, attention output, stream after attention, LayerNorm 2, fc1, GELU
-    float* P;                                 // attention probabilities [batch*heads*tokens, sld]
+    AT* P;                                    // attention probabilities [batch*heads*tokens, sld], in the storage type
     AT *N1B, *QKVB, *OB, *X2B, *N2B, *CB, *AB;
-    float *PB, *SB;                           // gradients of the probabilities / of the scores
+    AT *PB, *SB;                              // gradients of the probabilities / of the scores
   };
   struct ActSet {
     AT *VCOL = nullptr, *VPE = nullptr, *VCOLB = nullptr, *VPEB = nullptr;   // patch columns, patch embedding (+ grads)
@@ -282,7 +282,7 @@ struct Eng : mdd_engine {
       // norm2, mlp.fc1, mlp.fc2}, norm (oracle/vit_ref.py; reparam_module.py:28-39 flattens in this order)
       CHECK_ARG(S % vit.patch == 0, "image_size must be a multiple of the patch size");
       const int D = vit.dim, gp = S / vit.patch;
-      Tk = 1 + gp * gp; sld = (Tk + 3) & ~3;
+      Tk = 1 + gp * gp; sld = (Tk + 7) & ~7;
       CHECK_ARG(D % vit.heads == 0 && Tk <= 512, "heads must divide dim; at most 512 tokens");
       auto add_lin = [&](const std::string& name, int cin, int cout, int tokens, bool conv_shape) {
         ConvL L; L.cin = cin; L.cout = cout; L.k = 1; L.stride = 1; L.groups = 1; L.pad = 0;
@@ -860,13 +860,13 @@ struct Eng : mdd_engine {
       const AT *q = pa.QKV, *k = pa.QKV + D, *v = pa.QKV + 2 * D;
       const AT *q_t = T ? qa.QKV : nullptr, *k_t = T ? qa.QKV + D : nullptr, *v_t = T ? qa.QKV + 2 * D : nullptr;
       if (!T) {
-        VIT_RC(mdd_op_bgemm(bdt(), 0, 1, &ad.s, q, nullptr, k, nullptr, pa.P, nullptr, st));
-        VIT_RC(mdd_op_softmax(rows, Tk, sld, scale, pa.P, nullptr, pa.P, nullptr, st));
-        VIT_RC(mdd_op_bgemm(bdt(), 1, 0, &ad.o, pa.P, nullptr, v, nullptr, pa.O, nullptr, st));
+        VIT_RC(mdd_op_bgemm(bdt(), 0, 0, &ad.s, q, nullptr, k, nullptr, pa.P, nullptr, st));
+        VIT_RC(mdd_op_softmax(VDT, rows, Tk, sld, scale, pa.P, nullptr, pa.P, nullptr, st));
+        VIT_RC(mdd_op_bgemm(bdt(), 0, 0, &ad.o, pa.P, nullptr, v, nullptr, pa.O, nullptr, st));
       } else {
-        VIT_RC(mdd_op_bgemm(bdt(), 0, 1, &ad.s, q, q_t, k, k_t, nullptr, qa.P, st));
-        VIT_RC(mdd_op_softmax_bwd(rows, Tk, sld, scale, pa.P, nullptr, qa.P, nullptr, qa.P, nullptr, st));
-        VIT_RC(mdd_op_bgemm(bdt(), 1, 0, &ad.o, pa.P, qa.P, v, v_t, nullptr, qa.O, st));
+        VIT_RC(mdd_op_bgemm(bdt(), 0, 0, &ad.s, q, q_t, k, k_t, nullptr, qa.P, st));
+        VIT_RC(mdd_op_softmax_bwd(VDT, rows, Tk, sld, scale, pa.P, nullptr, qa.P, nullptr, qa.P, nullptr, st));
+        VIT_RC(mdd_op_bgemm(bdt(), 0, 0, &ad.o, pa.P, qa.P, v, v_t, nullptr, qa.O, st));
       }
       conv_fwd(T, convs[B.proj], pa.O, qa.O, P.TMP, Q.TMP, nullptr, nullptr, 1.f, th, th_t, st);
       launch_add2<AT>(pa.X2, T ? qa.X2 : nullptr, x, x_t, P.TMP, T ? Q.TMP : nullptr, (int64_t)M * D, st);
@@ -933,19 +933,19 @@ struct Eng : mdd_engine {
       const AT *q = pa.QKV, *k = pa.QKV + D, *v = pa.QKV + 2 * D;
       if (!T) {
         AT* z = oa.QKVB;
-        VIT_RC(mdd_op_bgemm(bdt(), 0, 1, &ad.dp, oa.OB, nullptr, v, nullptr, oa.PB, nullptr, st));
-        VIT_RC(mdd_op_softmax_bwd(rows, Tk, sld, scale, pa.P, nullptr, oa.PB, nullptr, oa.SB, nullptr, st));
-        VIT_RC(mdd_op_bgemm(bdt(), 1, 0, &ad.dv, pa.P, nullptr, oa.OB, nullptr, z + 2 * D, nullptr, st));
-        VIT_RC(mdd_op_bgemm(bdt(), 1, 0, &ad.dq, oa.SB, nullptr, k, nullptr, z, nullptr, st));
-        VIT_RC(mdd_op_bgemm(bdt(), 1, 0, &ad.dk, oa.SB, nullptr, q, nullptr, z + D, nullptr, st));
+        VIT_RC(mdd_op_bgemm(bdt(), 0, 0, &ad.dp, oa.OB, nullptr, v, nullptr, oa.PB, nullptr, st));
+        VIT_RC(mdd_op_softmax_bwd(VDT, rows, Tk, sld, scale, pa.P, nullptr, oa.PB, nullptr, oa.SB, nullptr, st));
+        VIT_RC(mdd_op_bgemm(bdt(), 0, 0, &ad.dv, pa.P, nullptr, oa.OB, nullptr, z + 2 * D, nullptr, st));
+        VIT_RC(mdd_op_bgemm(bdt(), 0, 0, &ad.dq, oa.SB, nullptr, k, nullptr, z, nullptr, st));
+        VIT_RC(mdd_op_bgemm(bdt(), 0, 0, &ad.dk, oa.SB, nullptr, q, nullptr, z + D, nullptr, st));
       } else {
         const AT *q_t = qa.QKV, *k_t = qa.QKV + D, *v_t = qa.QKV + 2 * D;
         AT* z = qa.QKVB;
-        VIT_RC(mdd_op_bgemm(bdt(), 0, 1, &ad.dp, oa.OB, qa.OB, v, v_t, nullptr, qa.PB, st));
-        VIT_RC(mdd_op_softmax_bwd(rows, Tk, sld, scale, pa.P, qa.P, oa.PB, qa.PB, nullptr, qa.SB, st));
-        VIT_RC(mdd_op_bgemm(bdt(), 1, 0, &ad.dv, pa.P, qa.P, oa.OB, qa.OB, nullptr, z + 2 * D, st));
-        VIT_RC(mdd_op_bgemm(bdt(), 1, 0, &ad.dq, oa.SB, qa.SB, k, k_t, nullptr, z, st));
-        VIT_RC(mdd_op_bgemm(bdt(), 1, 0, &ad.dk, oa.SB, qa.SB, q, q_t, nullptr, z + D, st));
+        VIT_RC(mdd_op_bgemm(bdt(), 0, 0, &ad.dp, oa.OB, qa.OB, v, v_t, nullptr, qa.PB, st));
+        VIT_RC(mdd_op_softmax_bwd(VDT, rows, Tk, sld, scale, pa.P, qa.P, oa.PB, qa.PB, nullptr, qa.SB, st));
+        VIT_RC(mdd_op_bgemm(bdt(), 0, 0, &ad.dv, pa.P, qa.P, oa.OB, qa.OB, nullptr, z + 2 * D, st));
+        VIT_RC(mdd_op_bgemm(bdt(), 0, 0, &ad.dq, oa.SB, qa.SB, k, k_t, nullptr, z, st));
+        VIT_RC(mdd_op_bgemm(bdt(), 0, 0, &ad.dk, oa.SB, qa.SB, q, q_t, nullptr, z + D, st));
       }
       lin_bwd_w(T, convs[B.qkv], oa.QKVB, qa.QKVB, pa.N1, qa.N1, gout, st);
       conv_bwd_d(T, convs[B.qkv], oa.QKVB, qa.QKVB, epi_lin(T ? qa.N1B : oa.N1B, nullptr), st);

@@ -238,9 +238,9 @@ __global__ void k_gelu_bwd(const AT* __restrict__ c, const AT* __restrict__ c_t,
 
 // ------------------------------------------------------------------ softmax over rows of fp32 scores (a wave per row)
 constexpr int SM_MAXE = 8;     // columns per lane: cols <= 512
-template <class S>
-__global__ __launch_bounds__(256) void k_softmax_fwd(const float* __restrict__ s, const float* __restrict__ s_t,
-                                                     float* __restrict__ p, float* __restrict__ p_t, int64_t rows,
+template <class S, class TS>
+__global__ __launch_bounds__(256) void k_softmax_fwd(const TS* __restrict__ s, const TS* __restrict__ s_t,
+                                                     TS* __restrict__ p, TS* __restrict__ p_t, int64_t rows,
                                                      int cols, int ld, float scale) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -265,10 +265,10 @@ __global__ __launch_bounds__(256) void k_softmax_fwd(const float* __restrict__ s
   }
 }
 // ds = scale * p * (dp - sum_j p_j dp_j)
-template <class S>
-__global__ __launch_bounds__(256) void k_softmax_bwd(const float* __restrict__ p, const float* __restrict__ p_t,
-                                                     const float* __restrict__ dp, const float* __restrict__ dp_t,
-                                                     float* __restrict__ ds, float* __restrict__ ds_t, int64_t rows,
+template <class S, class TS>
+__global__ __launch_bounds__(256) void k_softmax_bwd(const TS* __restrict__ p, const TS* __restrict__ p_t,
+                                                     const TS* __restrict__ dp, const TS* __restrict__ dp_t,
+                                                     TS* __restrict__ ds, TS* __restrict__ ds_t, int64_t rows,
                                                      int cols, int ld, float scale) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -779,6 +779,7 @@ template <bool DUAL>
 bool bgemm_mfma(const BG& p, int a_is_f32, int c_is_f32, dim3 grid, hipStream_t st) {
   if (!a_is_f32 && c_is_f32) k_bgemm_mfma<DUAL, bf16, float><<<grid, 256, 0, st>>>(p);
   else if (a_is_f32 && !c_is_f32) k_bgemm_mfma<DUAL, float, bf16><<<grid, 256, 0, st>>>(p);
+  else if (!a_is_f32 && !c_is_f32) k_bgemm_mfma<DUAL, bf16, bf16><<<grid, 256, 0, st>>>(p);   // scores stored as bf16 too
   else return false;
   return true;
 }
@@ -928,25 +929,39 @@ int mdd_op_gelu_bwd(int dtype, int64_t n, const void* c, const void* c_t, const 
   return 0;
 }
 
-int mdd_op_softmax(int64_t rows, int cols, int ld, float scale, const float* s, const float* s_t, float* p,
-                   float* p_t, void* stream) {
+int mdd_op_softmax(int dtype, int64_t rows, int cols, int ld, float scale, const void* s, const void* s_t, void* p,
+                   void* p_t, void* stream) {
   CHECK_ARG(rows > 0 && cols > 0 && cols <= 64 * SM_MAXE && ld >= cols && s, "rows / cols (<= 512) / ld");
   CHECK_ARG(s_t ? p_t != nullptr : p != nullptr, "output is null");
+  CHECK_ARG(dtype == MDD_DTYPE_F32 || dtype == MDD_DTYPE_BF16, "dtype");
   const unsigned grid = (unsigned)((rows + 3) / 4);
-  if (s_t) k_softmax_fwd<Dual><<<grid, 256, 0, (hipStream_t)stream>>>(s, s_t, p, p_t, rows, cols, ld, scale);
-  else k_softmax_fwd<float><<<grid, 256, 0, (hipStream_t)stream>>>(s, nullptr, p, nullptr, rows, cols, ld, scale);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MDD_DTYPE_F32) {
+    if (s_t) k_softmax_fwd<Dual, float><<<grid, 256, 0, st>>>((const float*)s, (const float*)s_t, (float*)p, (float*)p_t, rows, cols, ld, scale);
+    else k_softmax_fwd<float, float><<<grid, 256, 0, st>>>((const float*)s, nullptr, (float*)p, nullptr, rows, cols, ld, scale);
+  } else {
+    if (s_t) k_softmax_fwd<Dual, bf16><<<grid, 256, 0, st>>>((const bf16*)s, (const bf16*)s_t, (bf16*)p, (bf16*)p_t, rows, cols, ld, scale);
+    else k_softmax_fwd<float, bf16><<<grid, 256, 0, st>>>((const bf16*)s, nullptr, (bf16*)p, nullptr, rows, cols, ld, scale);
+  }
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
 
-int mdd_op_softmax_bwd(int64_t rows, int cols, int ld, float scale, const float* p, const float* p_t,
-                       const float* dp, const float* dp_t, float* ds, float* ds_t, void* stream) {
+int mdd_op_softmax_bwd(int dtype, int64_t rows, int cols, int ld, float scale, const void* p, const void* p_t,
+                       const void* dp, const void* dp_t, void* ds, void* ds_t, void* stream) {
   CHECK_ARG(rows > 0 && cols > 0 && cols <= 64 * SM_MAXE && ld >= cols && p && dp, "rows / cols (<= 512) / ld");
   const bool T = p_t != nullptr;
   CHECK_ARG(T == (dp_t != nullptr) && (T ? ds_t != nullptr : ds != nullptr), "tangent operands come together");
+  CHECK_ARG(dtype == MDD_DTYPE_F32 || dtype == MDD_DTYPE_BF16, "dtype");
   const unsigned grid = (unsigned)((rows + 3) / 4);
-  if (T) k_softmax_bwd<Dual><<<grid, 256, 0, (hipStream_t)stream>>>(p, p_t, dp, dp_t, ds, ds_t, rows, cols, ld, scale);
-  else k_softmax_bwd<float><<<grid, 256, 0, (hipStream_t)stream>>>(p, nullptr, dp, nullptr, ds, nullptr, rows, cols, ld, scale);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MDD_DTYPE_F32) {
+    if (T) k_softmax_bwd<Dual, float><<<grid, 256, 0, st>>>((const float*)p, (const float*)p_t, (const float*)dp, (const float*)dp_t, (float*)ds, (float*)ds_t, rows, cols, ld, scale);
+    else k_softmax_bwd<float, float><<<grid, 256, 0, st>>>((const float*)p, nullptr, (const float*)dp, nullptr, (float*)ds, nullptr, rows, cols, ld, scale);
+  } else {
+    if (T) k_softmax_bwd<Dual, bf16><<<grid, 256, 0, st>>>((const bf16*)p, (const bf16*)p_t, (const bf16*)dp, (const bf16*)dp_t, (bf16*)ds, (bf16*)ds_t, rows, cols, ld, scale);
+    else k_softmax_bwd<float, bf16><<<grid, 256, 0, st>>>((const bf16*)p, nullptr, (const bf16*)dp, nullptr, (bf16*)ds, nullptr, rows, cols, ld, scale);
+  }
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

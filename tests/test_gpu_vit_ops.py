@@ -138,11 +138,11 @@ def test_softmax_forward_backward_and_tangents(rows, cols, ld, report):
     sd, std, dpd, dptd = pad(s), pad(st_), pad(dp), pad(dpt)
     p, pt, ds, dst = (torch.zeros(rows, ld, device=DEV) for _ in range(4))
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    mod.check(lib.mdd_op_softmax(rows, cols, ld, scale, P(sd), None, P(p), None, st))
-    mod.check(lib.mdd_op_softmax(rows, cols, ld, scale, P(sd), P(std), P(p), P(pt), st))
+    mod.check(lib.mdd_op_softmax(0, rows, cols, ld, scale, P(sd), None, P(p), None, st))
+    mod.check(lib.mdd_op_softmax(0, rows, cols, ld, scale, P(sd), P(std), P(p), P(pt), st))
     # the backward consumes the probabilities and their tangents (as the engine will: both are stashed)
-    mod.check(lib.mdd_op_softmax_bwd(rows, cols, ld, scale, P(p), None, P(dpd), None, P(ds), None, st))
-    mod.check(lib.mdd_op_softmax_bwd(rows, cols, ld, scale, P(p), P(pt), P(dpd), P(dptd), P(ds), P(dst), st))
+    mod.check(lib.mdd_op_softmax_bwd(0, rows, cols, ld, scale, P(p), None, P(dpd), None, P(ds), None, st))
+    mod.check(lib.mdd_op_softmax_bwd(0, rows, cols, ld, scale, P(p), P(pt), P(dpd), P(dptd), P(ds), P(dst), st))
     torch.cuda.synchronize()
     cut = lambda t: back(t)[:, :cols]
     e = dict(p=rel_err(cut(p), p_ref), p_t=rel_err(cut(pt), pt_ref), ds=rel_err(cut(ds), ds_ref),
@@ -150,6 +150,35 @@ def test_softmax_forward_backward_and_tangents(rows, cols, ld, report):
     report(f"softmax {rows}x{cols} (ld {ld}): " + " ".join(f"{k} {float(v):.1e}" for k, v in e.items()))
     assert all(float(v) < 2e-6 for v in e.values()), e
     assert float(p[:, cols:].abs().max() if ld > cols else 0.0) == 0.0      # the padding columns are never written
+
+
+def test_softmax_on_bf16_scores(report):
+    """the engine's bf16 mode keeps scores / probabilities / their gradients in bf16 (dtype 1)"""
+    mod, lib = _lib()
+    rows, cols, ld = 12 * 197, 197, 200
+    g = torch.Generator().manual_seed(1)
+    rnd = lambda: torch.randn(rows, cols, generator=g, dtype=torch.float64)
+    pad = lambda t: torch.nn.functional.pad(t, (0, ld - cols)).to(DEV, torch.bfloat16).contiguous()
+    sd, std, dpd, dptd = pad(rnd() * 3), pad(rnd()), pad(rnd()), pad(rnd())
+    s, st_, dp, dpt = (back(t)[:, :cols] for t in (sd, std, dpd, dptd))
+    scale = 0.125
+    f = lambda a: torch.softmax(a * scale, -1)
+    p_ref, pt_ref = jvp(f, (s,), (st_,))
+    p, pt, ds, dst = (torch.zeros(rows, ld, device=DEV, dtype=torch.bfloat16) for _ in range(4))
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    mod.check(lib.mdd_op_softmax(1, rows, cols, ld, scale, P(sd), None, P(p), None, st))
+    mod.check(lib.mdd_op_softmax(1, rows, cols, ld, scale, P(sd), P(std), P(p), P(pt), st))
+    # backward from the ROUNDED probabilities the device holds (that is what the engine stashes)
+    pr, ptr = back(p)[:, :cols], back(pt)[:, :cols]
+    ds_ref = scale * pr * (dp - (pr * dp).sum(-1, keepdim=True))
+    dst_ref = scale * (ptr * (dp - (pr * dp).sum(-1, keepdim=True)) + pr * (dpt - (ptr * dp + pr * dpt).sum(-1, keepdim=True)))
+    mod.check(lib.mdd_op_softmax_bwd(1, rows, cols, ld, scale, P(p), None, P(dpd), None, P(ds), None, st))
+    mod.check(lib.mdd_op_softmax_bwd(1, rows, cols, ld, scale, P(p), P(pt), P(dpd), P(dptd), P(ds), P(dst), st))
+    torch.cuda.synchronize()
+    e = dict(p=rel_err(pr, p_ref), p_t=rel_err(ptr, pt_ref), ds=rel_err(back(ds)[:, :cols], ds_ref),
+             ds_t=rel_err(back(dst)[:, :cols], dst_ref))
+    report("softmax on bf16 scores: " + " ".join(f"{k} {float(v):.1e}" for k, v in e.items()))
+    assert all(float(v) < 5e-3 for v in e.values()), e
 
 
 def _desc(mod, **kw):
@@ -223,12 +252,12 @@ def test_attention_layer_composed_from_the_ops(dtype, report):
         tq = (lambda t, o: None if t is None else off(t, o))
         # forward
         bg(0, 1, d_s, off(z, q0), tq(zt, q0), off(z, k0), tq(zt, k0), P(S), P(St) if tangent else None)
-        mod.check(lib.mdd_op_softmax(rows, T, ld, scale, P(S), P(St) if tangent else None, P(Pm), P(Pt) if tangent else None, st))
+        mod.check(lib.mdd_op_softmax(0, rows, T, ld, scale, P(S), P(St) if tangent else None, P(Pm), P(Pt) if tangent else None, st))
         bg(1, 0, d_o, P(Pm), P(Pt) if tangent else None, off(z, v0), tq(zt, v0), P(O), P(Ot) if tangent else None)
         # backward
         g_, gt_ = dod, (dotd if tangent else None)
         bg(0, 1, d_dp, P(g_), P(gt_), off(z, v0), tq(zt, v0), P(dP), P(dPt) if tangent else None)
-        mod.check(lib.mdd_op_softmax_bwd(rows, T, ld, scale, P(Pm), P(Pt) if tangent else None, P(dP),
+        mod.check(lib.mdd_op_softmax_bwd(0, rows, T, ld, scale, P(Pm), P(Pt) if tangent else None, P(dP),
                                          P(dPt) if tangent else None, P(dS), P(dSt) if tangent else None, st))
         out, outt = dZ, (dZt if tangent else None)
         bg(1, 0, d_dv, P(Pm), P(Pt) if tangent else None, P(g_), P(gt_), off(out, v0), tq(outt, v0))
