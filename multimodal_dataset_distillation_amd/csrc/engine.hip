@@ -315,6 +315,11 @@ struct Eng : mdd_engine {
                 "dims must be multiples of the 16-byte chunk");
       P_img = off; feat = D;
       stem[0] = stem[1] = stem[2] = stem[3] = fin = -1;
+      for (auto& L : convs) {
+        LinPackDesc d; d.off_w = L.off_w; d.off_p = L.off_p; d.out = L.cout; d.in = L.cin; d.tile_start = lpd_tiles; d.pad_ = 0;
+        lpd_tiles += ((L.cin + 31) / 32) * ((L.cout + 31) / 32);
+        lpd.push_back(d);
+      }
     } else {
     // stem 'deep_quad': 3x3 convs, channels (sc/8, sc/4, sc/2, sc), strides (2,1,1,2)
     int sc = nf.stem_chs, chs[4] = {sc / 8, sc / 4, sc / 2, sc}, strides[4] = {2, 1, 1, 2};
@@ -480,6 +485,7 @@ struct Eng : mdd_engine {
   void plan_workspace() {
     arena = Arena(); fix.clear(); names.clear();
     o_descs = arena.take((int64_t)descs.size() * sizeof(WsDesc));
+    o_lpd = arena.take((int64_t)lpd.size() * sizeof(LinPackDesc));
     plan(&wf, packed_total, "wf", -2); plan(&wt, packed_total, "wt", -2);
     plan(&wf_t, packed_total, "wf_t", -2); plan(&wt_t, packed_total, "wt_t", -2);
     int64_t dsmax = 0, dfmax = 0;
@@ -546,6 +552,9 @@ struct Eng : mdd_engine {
     if (!descs.empty())
       HIP_CHECK_RET(hipMemcpyAsync(d_descs, descs.data(), descs.size() * sizeof(WsDesc),
                                    hipMemcpyHostToDevice, st));
+    d_lpd = (LinPackDesc*)(base + o_lpd);
+    if (!lpd.empty())
+      HIP_CHECK_RET(hipMemcpyAsync(d_lpd, lpd.data(), lpd.size() * sizeof(LinPackDesc), hipMemcpyHostToDevice, st));
     // packed weight buffers carry zero padding (conv1: 3 -> 8 input channels) that is never rewritten
     HIP_CHECK_RET(hipMemsetAsync(wf, 0, packed_total * sizeof(AT), st));
     HIP_CHECK_RET(hipMemsetAsync(wt, 0, packed_total * sizeof(AT), st));
@@ -800,11 +809,9 @@ struct Eng : mdd_engine {
   static constexpr int VDT = sizeof(AT) == 4 ? MDD_DTYPE_F32 : MDD_DTYPE_BF16;
   // the attention contractions follow the engine's precision mode: exact FMA (f32), split-bf16 MFMA (bf16x2), bf16 MFMA
   int bdt() const { return sizeof(AT) == 4 ? (prec == 1 ? MDD_DTYPE_BF16X2 : MDD_DTYPE_F32) : MDD_DTYPE_BF16; }
+  std::vector<LinPackDesc> lpd; LinPackDesc* d_lpd = nullptr; int64_t o_lpd = 0; int lpd_tiles = 0;
   void vit_pack(const float* th, const float* th_t, hipStream_t st) {
-    for (auto& L : convs) {
-      launch_lin_pack<AT>(wf + L.off_p, wt + L.off_p, th + L.off_w, L.cout, L.cin, st);
-      if (th_t) launch_lin_pack<AT>(wf_t + L.off_p, wt_t + L.off_p, th_t + L.off_w, L.cout, L.cin, st);
-    }
+    launch_lin_pack_all<AT>(d_lpd, (int)lpd.size(), lpd_tiles, th, th_t, wf, wt, wf_t, wt_t, st);
   }
   // the weight gradient of a linear goes to gout + off_w: conv_bwd_w adds the layer's PACKED offset to its base
   void lin_bwd_w(bool T, const ConvL& L, const AT* dy, const AT* dy_t, const AT* x, const AT* x_t, float* gout,

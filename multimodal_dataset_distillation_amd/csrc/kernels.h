@@ -232,3 +232,6 @@ template <class AT> void launch_cls_scatter(AT* xb, const AT* in, int n, int tok
 template <class AT> void launch_act_to_f32(float* o, const AT* a, int64_t n, hipStream_t st);
 template <class AT> void launch_f32_to_act(AT* o, const float* a, int64_t n, hipStream_t st);
 template <class AT> void launch_lin_pack(AT* wf, AT* wt, const float* w, int out, int in, hipStream_t st);
+struct LinPackDesc { int64_t off_w, off_p; int out, in, tile_start, pad_; };
+template <class AT> void launch_lin_pack_all(const LinPackDesc* descs, int nd, int total_tiles, const float* th, const float* th_t,
+                                             AT* wf, AT* wt, AT* wf_t, AT* wt_t, hipStream_t st);

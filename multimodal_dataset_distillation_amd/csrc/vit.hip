@@ -837,6 +837,45 @@ template <class AT> void launch_f32_to_act(AT* o, const float* a, int64_t n, hip
 template <class AT> void launch_lin_pack(AT* wf, AT* wt, const float* w, int out, int in, hipStream_t st) {
   k_lin_pack<AT><<<dim3((in + 31) / 32, (out + 31) / 32), 256, 0, st>>>(wf, wt, w, out, in);
 }
+// every linear of the network (and, with theta_t, its tangent) in ONE launch: block -> (layer, 32x32 tile) by the
+// layers' tile prefix sums
+template <class AT>
+__global__ void k_lin_pack_all(const LinPackDesc* __restrict__ descs, int nd, const float* __restrict__ th,
+                               const float* __restrict__ th_t, AT* __restrict__ wf, AT* __restrict__ wt,
+                               AT* __restrict__ wf_t, AT* __restrict__ wt_t) {
+  __shared__ float tile[2][32][33];
+  int li = 0;
+  while (li + 1 < nd && (int)blockIdx.x >= descs[li + 1].tile_start) ++li;
+  const LinPackDesc d = descs[li];
+  const int t = blockIdx.x - d.tile_start, tpr = (d.in + 31) / 32;
+  const int i0 = (t % tpr) * 32, o0 = (t / tpr) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* w = th + d.off_w; const float* w_t = th_t ? th_t + d.off_w : nullptr;
+  for (int r = ty; r < 32; r += 8) {
+    const int o = o0 + r, i = i0 + tx;
+    float v = 0.f, vt = 0.f;
+    if (o < d.out && i < d.in) {
+      const int64_t idx = (int64_t)o * d.in + i;
+      v = w[idx]; wf[d.off_p + idx] = from_f<AT>(v);
+      if (w_t) { vt = w_t[idx]; wf_t[d.off_p + idx] = from_f<AT>(vt); }
+    }
+    tile[0][r][tx] = v; tile[1][r][tx] = vt;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int i = i0 + r, o = o0 + tx;
+    if (o < d.out && i < d.in) {
+      const int64_t idx = (int64_t)i * d.out + o;
+      wt[d.off_p + idx] = from_f<AT>(tile[0][tx][r]);
+      if (w_t) wt_t[d.off_p + idx] = from_f<AT>(tile[1][tx][r]);
+    }
+  }
+}
+template <class AT>
+void launch_lin_pack_all(const LinPackDesc* descs, int nd, int total_tiles, const float* th, const float* th_t,
+                         AT* wf, AT* wt, AT* wf_t, AT* wt_t, hipStream_t st) {
+  k_lin_pack_all<AT><<<total_tiles, 256, 0, st>>>(descs, nd, th, th_t, wf, wt, wf_t, wt_t);
+}
 #define VIT_INST(AT)                                                                                              \
   template void launch_patchify<AT>(AT*, const float*, const int64_t*, int, int, int, hipStream_t);               \
   template void launch_unpatchify_accum<AT>(float*, const AT*, const int64_t*, const float*, float, int, int, int, \
@@ -849,7 +888,9 @@ template <class AT> void launch_lin_pack(AT* wf, AT* wt, const float* w, int out
   template void launch_cls_scatter<AT>(AT*, const AT*, int, int, int, hipStream_t);                               \
   template void launch_act_to_f32<AT>(float*, const AT*, int64_t, hipStream_t);                                   \
   template void launch_f32_to_act<AT>(AT*, const float*, int64_t, hipStream_t);                                   \
-  template void launch_lin_pack<AT>(AT*, AT*, const float*, int, int, hipStream_t);
+  template void launch_lin_pack<AT>(AT*, AT*, const float*, int, int, hipStream_t);                               \
+  template void launch_lin_pack_all<AT>(const LinPackDesc*, int, int, const float*, const float*, AT*, AT*, AT*, AT*, \
+                                        hipStream_t);
 VIT_INST(float)
 VIT_INST(bf16)
 #undef VIT_INST
