@@ -97,12 +97,17 @@ COMM_ID_BYTES = 128   # include/mdd_hip.h MDD_COMM_ID_BYTES
 _lib = None
 
 
-def load():
-    """Load libmdd_hip.so and bind every declared symbol.  Raises (never falls back)."""
+def load(variant=None):
+    """Load libmdd_hip.so and bind every declared symbol.  Raises (never falls back).
+
+    The product path always loads the in-tree library: no environment variable can swap it (MDD_HIP_LIB is
+    ignored; distill.py / buffer.py record any MDD_* variable they see).  Kernel-variant experiments under tools/
+    pass the variant library's path explicitly (`load(variant=...)`, or set `_lib.LIB_PATH` before the first load).
+    """
     global _lib
     if _lib is not None:
         return _lib
-    path = os.environ.get("MDD_HIP_LIB", LIB_PATH)   # kernel-variant experiments (tools/variants.sh)
+    path = variant if variant is not None else LIB_PATH
     if not os.path.exists(path):
         raise RuntimeError(
             "libmdd_hip.so is not built (%s). Run `python -m multimodal_dataset_distillation_amd."
@@ -117,6 +122,11 @@ def load():
                            % (lib.mdd_version(), ABI_VERSION))
     _lib = lib
     return lib
+
+
+def stray_env():
+    """MDD_* variables present in the environment (none of them changes what the product library does)."""
+    return sorted(k for k in os.environ if k.startswith("MDD_"))
 
 
 def check(rc):

@@ -141,7 +141,7 @@ struct KArgs {
   int M, mtiles, ntiles, dbg;
 };
 
-template <class AT, int WGM, int WGN, int TM, int TN, int MODE, bool KFULL, int PREC>
+template <class AT, int WGM, int WGN, int TM, int TN, int MODE, bool KFULL, int PREC, bool IBK = false>
 __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   constexpr int RA = BM / 32, RB = BN / 32;
@@ -575,9 +575,14 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
   const bool nomath = (MDD_DBG_BITS(p) & 16) != 0;                   // dbg bit4: no activation math (timing only)
   const bool nostore = (MDD_DBG_BITS(p) & 2) != 0;                   // dbg bit1: no stores (timing only)
   const float beta = E.beta;
-  auto run = [&](auto EMc, auto FTc) __attribute__((always_inline)) {
+  auto run = [&](auto EMc, auto FTc, auto IBc) __attribute__((always_inline)) {
     constexpr int EM = decltype(EMc)::value;
     constexpr bool FULLT = decltype(FTc)::value;   // every row of the block tile is a real output row
+    // per-image bias (data-gradient modes): the accumulator row of pixel m gets ib[m / hw][channel] * ib_mul
+    // added -- the pooled squeeze-excite path's gradient, broadcast over the pixels of its image
+    constexpr bool IB = IBK && decltype(IBc)::value && (EM == EPI_BWD || EM == EPI_BWD_T);
+    const float* ibp = EM == EPI_BWD_T ? E.ib_t : E.ib;
+    const float ib_inv = IB ? 1.f / (float)E.ib_hw : 0.f;
     constexpr bool HAS_C = EM == EPI_FWD_T || EM == EPI_BWD || EM == EPI_BWD_T;   // stashed pre-activation
     constexpr bool HAS_T = EM == EPI_BWD_T;                                       // its tangent + a-bar
     constexpr bool HAS_ACT = EM != EPI_BWD_LIN;
@@ -603,11 +608,22 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
         int idx[UU];
         bool ok[UU];
         uint4 q_a1[UU], q_c[UU], q_ct[UU], q_ab[UU], q_a2[UU];
+        float4 q_ib[IB ? UU : 1][IB ? CE / 4 : 1];
 #pragma unroll
         for (int u = 0; u < UU; ++u) {
           const int row = (ps0 + u) * RPP + lrow;
           int m = m0 + wm * WROWS + hi * 32 + row;
           ok[u] = FULLT || m < e_M;
+          if constexpr (IB) {
+            if (ok[u]) {
+              int img = (int)((float)m * ib_inv);            // estimate, then exact by one correction step
+              const int rem = m - img * E.ib_hw;
+              img += rem >= E.ib_hw ? 1 : (rem < 0 ? -1 : 0);
+              const float* q = ibp + (size_t)img * G.co_tot + ch;
+#pragma unroll
+              for (int e = 0; e < CE / 4; ++e) q_ib[u][e] = *(const float4*)(q + 4 * e);
+            }
+          }
           if constexpr (MODE == 2) {   // class-local pixel -> full-resolution output pixel
             int oxc = m % e_wo, t = m / e_wo;
             int oyc = t % e_ho, ni = t / e_ho;
@@ -639,6 +655,13 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
 #pragma unroll
             for (int e = 0; e < CE; ++e) v[e] += t0[e];
           }
+          if constexpr (IB) {
+#pragma unroll
+            for (int e = 0; e < CE / 4; ++e) {
+              v[4 * e] += q_ib[u][e].x * E.ib_mul; v[4 * e + 1] += q_ib[u][e].y * E.ib_mul;
+              v[4 * e + 2] += q_ib[u][e].z * E.ib_mul; v[4 * e + 3] += q_ib[u][e].w * E.ib_mul;
+            }
+          }
           if (out_raw && !nostore) *(uint4*)(out_raw + idx[u]) = Chunk<AT>::pack(v);
           if constexpr (HAS_ACT) {
             if (!do_act) continue;
@@ -669,23 +692,30 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
     }
   };
   const bool full_tile = MODE != 2 && m0 + BM <= e_M;
-#define MDD_RUN(EMV)                                                                         \
-  do {                                                                                       \
-    if (MODE != 2 && full_tile) run(std::integral_constant<int, EMV>{}, std::true_type{});   \
-    else run(std::integral_constant<int, EMV>{}, std::false_type{});                         \
+#define MDD_RUN(EMV, IBV)                                                                              \
+  do {                                                                                                 \
+    if (MODE != 2 && full_tile) run(std::integral_constant<int, EMV>{}, std::true_type{}, IBV{});     \
+    else run(std::integral_constant<int, EMV>{}, std::false_type{}, IBV{});                           \
   } while (0)
-  switch (E.mode) {
-    case EPI_FWD: MDD_RUN(EPI_FWD); break;
-    case EPI_FWD_T: MDD_RUN(EPI_FWD_T); break;
-    case EPI_BWD: MDD_RUN(EPI_BWD); break;
-    case EPI_BWD_T: MDD_RUN(EPI_BWD_T); break;
-    default: MDD_RUN(EPI_BWD_LIN); break;
+  // the per-image bias exists only on pointwise data gradients (conv3 of a residual block): those launches
+  // use the IBK instance of the kernel, which contains nothing but the two epilogues that take it
+  if constexpr (IBK) {
+    if (E.mode == EPI_BWD) MDD_RUN(EPI_BWD, std::true_type);
+    else MDD_RUN(EPI_BWD_T, std::true_type);
+  } else {
+    switch (E.mode) {
+      case EPI_FWD: MDD_RUN(EPI_FWD, std::false_type); break;
+      case EPI_FWD_T: MDD_RUN(EPI_FWD_T, std::false_type); break;
+      case EPI_BWD: MDD_RUN(EPI_BWD, std::false_type); break;
+      case EPI_BWD_T: MDD_RUN(EPI_BWD_T, std::false_type); break;
+      default: MDD_RUN(EPI_BWD_LIN, std::false_type); break;
+    }
   }
 #undef MDD_RUN
 }
 
 
-template <class AT, int WGM, int WGN, int TM, int TN, int MODE, bool KFULL, int PREC>
+template <class AT, int WGM, int WGN, int TM, int TN, int MODE, bool KFULL, int PREC, bool IBK = false>
 void launch_cfg(const KArgs& a, hipStream_t st) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   KArgs k = a;
@@ -702,13 +732,13 @@ void launch_cfg(const KArgs& a, hipStream_t st) {
   (void)hipGetDevice(&dev);
   const uint64_t bit = 1ull << (dev & 63);
   if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_conv_gemm<AT, WGM, WGN, TM, TN, MODE, KFULL, PREC>,
+    hipError_t e = hipFuncSetAttribute((const void*)k_conv_gemm<AT, WGM, WGN, TM, TN, MODE, KFULL, PREC, IBK>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        MODE == 4 ? (int)MODE4_MAX_LDS : (int)shm);
     if (e == hipSuccess) attr_devs.fetch_or(bit, std::memory_order_release);
   }
   int64_t blocks = (int64_t)k.mtiles * k.ntiles * a.g.groups;
-  k_conv_gemm<AT, WGM, WGN, TM, TN, MODE, KFULL, PREC><<<(unsigned)blocks, 256, shm, st>>>(k);
+  k_conv_gemm<AT, WGM, WGN, TM, TN, MODE, KFULL, PREC, IBK><<<(unsigned)blocks, 256, shm, st>>>(k);
 }
 
 }  // namespace
@@ -734,6 +764,8 @@ void launch_conv_gemm(const ConvGeom& g, const AT* A1, const AT* B1, const AT* A
   const bool s2t = g.transposed && g.stride == 2;
   const int mode = pw ? 0 : (s2t ? (((g.ho | g.wo) & 1) == 0 && g.k <= 3 ? 2 : 3) : 1);
   const bool kfull = ((g.k * g.k * g.kc) % Mma<AT>::KE) == 0;
+  // per-image bias (ConvEpi::ib): pointwise data gradients with an activation epilogue only
+  const bool ibk = ep.ib != nullptr && mode == 0 && (ep.mode == EPI_BWD || ep.mode == EPI_BWD_T);
   if constexpr (sizeof(AT) == 2) {
     // MODE 4: 3x3 stride-1 "same" conv (forward or data gradient) whose group is one 128-byte channel row
     const bool slab = g.k == 3 && g.stride == 1 && g.pad == 1 && g.kc == 64 && g.nc <= 64 && g.ha == g.ho &&
@@ -742,7 +774,9 @@ void launch_conv_gemm(const ConvGeom& g, const AT* A1, const AT* B1, const AT* A
   }
 #define MDD_DISPATCH_P(WGM, WGN, TM, TN, PREC)                                                \
   do {                                                                                        \
-    if (mode == 0) { if (kfull) launch_cfg<AT, WGM, WGN, TM, TN, 0, true, PREC>(a, st);      \
+    if (mode == 0 && ibk) { if (kfull) launch_cfg<AT, WGM, WGN, TM, TN, 0, true, PREC, true>(a, st);   \
+                            else launch_cfg<AT, WGM, WGN, TM, TN, 0, false, PREC, true>(a, st); }      \
+    else if (mode == 0) { if (kfull) launch_cfg<AT, WGM, WGN, TM, TN, 0, true, PREC>(a, st);            \
                      else launch_cfg<AT, WGM, WGN, TM, TN, 0, false, PREC>(a, st); }         \
     else if (mode == 1) { if (kfull) launch_cfg<AT, WGM, WGN, TM, TN, 1, true, PREC>(a, st); \
                           else launch_cfg<AT, WGM, WGN, TM, TN, 1, false, PREC>(a, st); }    \

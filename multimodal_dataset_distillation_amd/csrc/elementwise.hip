@@ -258,12 +258,16 @@ __global__ void k_avgpool2_bwd(AT* __restrict__ din, const AT* __restrict__ dout
 // ------------------------------------------------------------------ per-(n,c) reductions over h*w
 // block = 256 threads = 8 chunk columns x 32 hw lanes.  MODE 0: mean x ; 1: mean silu(x) ;
 // 2: d = ga * sum a*b, then the sigmoid backward of the SE gate: out = d*g*(1-g)
+// 3: MODE 2, and the gradient w.r.t. conv3's output is written in the same pass: cb = a * g * ga
+//    (a = grad of the block output, b = conv3 output; the pooled path's share of that gradient reaches the
+//    residual branch through the mid-channel pooled vector instead -- see Eng::img_backward)
 template <class S, class AT, int MODE>
 __global__ void k_hw_reduce(float* __restrict__ out, float* __restrict__ out_t,
                             const AT* __restrict__ a, const AT* __restrict__ a_t,
                             const AT* __restrict__ b, const AT* __restrict__ b_t,
                             const float* __restrict__ gate, const float* __restrict__ gate_t,
-                            float mul, int hw, int c) {
+                            float mul, int hw, int c, AT* __restrict__ cb = nullptr,
+                            AT* __restrict__ cb_t = nullptr) {
   constexpr int CE = Chunk<AT>::N;
   int cch = c / CE;
   int colgroups = (cch + 7) / 8;
@@ -275,10 +279,21 @@ __global__ void k_hw_reduce(float* __restrict__ out, float* __restrict__ out_t,
 #pragma unroll
   for (int e = 0; e < CE; ++e) acc[e] = mk<S>(0.f, 0.f);
   if (col < cch) {
+    S gs[MODE == 3 ? CE : 1];
+    if constexpr (MODE == 3) {
+#pragma unroll
+      for (int e = 0; e < CE; ++e) gs[e] = ldS<S>(gate, gate_t, (size_t)ni * c + (size_t)col * CE + e) * mul;
+    }
     for (int p = lane; p < hw; p += 32) {
       int64_t ci = ((int64_t)ni * hw + p) * cch + col;
       S x[CE];
       ld_chunkS<S, AT>(a, a_t, ci, x);
+      if constexpr (MODE == 3) {
+        S o[CE];
+#pragma unroll
+        for (int e = 0; e < CE; ++e) o[e] = x[e] * gs[e];
+        st_chunkS<S, AT>(cb, cb_t, ci, o);
+      }
       if constexpr (MODE == 0) {
 #pragma unroll
         for (int e = 0; e < CE; ++e) acc[e] = acc[e] + x[e];
@@ -314,7 +329,7 @@ __global__ void k_hw_reduce(float* __restrict__ out, float* __restrict__ out_t,
     }
     int64_t oi = (int64_t)ni * c + (int64_t)ccol * CE + e;
     S r = mk<S>(sv * mul, stn * mul);
-    if constexpr (MODE == 2) {
+    if constexpr (MODE >= 2) {
       S g = ldS<S>(gate, gate_t, oi);
       r = r * g * (1.f - g);
     }
@@ -588,6 +603,18 @@ void launch_se_gate_grad(float* zbar, float* zbar_t, const AT* xbar, const AT* x
                                                              nullptr, gate, nullptr, ga, hw, c);
 }
 template <class AT>
+void launch_se_gate_grad_c3b(float* zbar, float* zbar_t, AT* c3bar, AT* c3bar_t, const AT* xbar, const AT* xbar_t,
+                             const AT* c3, const AT* c3_t, const float* gate, const float* gate_t, float ga, int n,
+                             int hw, int c, hipStream_t st) {
+  int colgroups = (c / Chunk<AT>::N + 7) / 8;
+  if (xbar_t)
+    k_hw_reduce<Dual, AT, 3><<<n * colgroups, 256, 0, st>>>(zbar, zbar_t, xbar, xbar_t, c3, c3_t, gate, gate_t, ga,
+                                                            hw, c, c3bar, c3bar_t);
+  else
+    k_hw_reduce<float, AT, 3><<<n * colgroups, 256, 0, st>>>(zbar, nullptr, xbar, nullptr, c3, nullptr, gate,
+                                                             nullptr, ga, hw, c, c3bar, nullptr);
+}
+template <class AT>
 void launch_se_apply_bwd(AT* c3bar, AT* c3bar_t, const AT* xbar, const AT* xbar_t,
                          const float* gate, const float* gate_t, const float* pbar,
                          const float* pbar_t, float ga, int n, int hw, int c, hipStream_t st) {
@@ -659,6 +686,8 @@ void launch_final_pool_bwd(AT* cfbar, AT* cfbar_t, const float* ybar, const floa
   template void launch_se_gate_grad<AT>(float*, float*, const AT*, const AT*, const AT*,           \
                                         const AT*, const float*, const float*, float, int, int,    \
                                         int, hipStream_t);                                         \
+  template void launch_se_gate_grad_c3b<AT>(float*, float*, AT*, AT*, const AT*, const AT*, const AT*, const AT*, \
+                                            const float*, const float*, float, int, int, int, hipStream_t);      \
   template void launch_se_apply_bwd<AT>(AT*, AT*, const AT*, const AT*, const float*,              \
                                         const float*, const float*, const float*, float, int, int, \
                                         int, hipStream_t);                                         \

@@ -40,6 +40,9 @@ int mdd_set_error_msg(int code, const char* msg) {
 #ifndef MDD_SIDE_PRIORITY
 #define MDD_SIDE_PRIORITY 0   // bit 0: weight-gradient stream at least priority; bit 1: text stream (experiment builds)
 #endif
+#ifndef MDD_SE_SIDE
+#define MDD_SE_SIDE 2            // forward passes: squeeze-excite gate chain beside conv3 -- 0: no (main stream),
+#endif                           // 1: on the side stream, 2: on a stream of its own with high queue priority
 #ifndef MDD_GRAPH
 #define MDD_GRAPH 0      // 1: mdd_unrolled_match replays a captured hipGraph (experiment build)
 #endif
@@ -188,9 +191,9 @@ struct Eng : mdd_engine {
   // ---------------- workspace plan (byte offsets), resolved to pointers at bind()
   struct BlockActs {
     AT *P, *SC, *C1, *A1, *C2, *A2, *C2b, *A2b, *C3;
-    float *p, *h, *gate;
+    float *q, *p, *h, *gate;   // SE: mid-channel pooled vector, its image under conv3 (= pooled conv3 output), MLP
     AT *C3B, *A2bB, *C2bB, *A2B, *C2B, *A1B, *C1B, *AinB;
-    float *zB, *hB, *pB;
+    float *zB, *hB, *pB, *qB;
   };
   struct VitActs {
     AT *N1, *QKV, *O, *X2, *N2, *C, *A;       // LayerNorm 1, fused qkv, attention output, stream after attention, LayerNorm 2, fc1, GELU
@@ -461,6 +464,7 @@ struct Eng : mdd_engine {
       plan(&a.C2, eout * B.mid, (p + "C2").c_str(), slot);  plan(&a.A2, eout * B.mid, (p + "A2").c_str(), slot);
       plan(&a.C2b, eout * B.mid, (p + "C2b").c_str(), slot); plan(&a.A2b, eout * B.mid, (p + "A2b").c_str(), slot);
       plan(&a.C3, eout * B.cout, (p + "C3").c_str(), slot);
+      plan(&a.q, n * B.mid, (p + "q").c_str(), slot); plan(&a.qB, n * B.mid, (p + "qB").c_str(), slot);
       plan(&a.p, n * B.se.c, (p + "p").c_str(), slot); plan(&a.h, n * B.se.rd, (p + "h").c_str(), slot);
       plan(&a.gate, n * B.se.c, (p + "gate").c_str(), slot);
       plan(&a.C3B, eout * B.cout, (p + "C3B").c_str(), slot);
@@ -579,6 +583,11 @@ struct Eng : mdd_engine {
       if (use_side) HIP_CHECK_RET(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
       if (use_side) HIP_CHECK_RET(hipStreamCreateWithFlags(&tside, hipStreamNonBlocking));
 #endif
+      if (use_side && MDD_SE_SIDE == 2) {
+        int prio_lo_ = 0, prio_hi_ = 0;
+        HIP_CHECK_RET(hipDeviceGetStreamPriorityRange(&prio_lo_, &prio_hi_));   // hi = greatest priority (smallest number)
+        HIP_CHECK_RET(hipStreamCreateWithPriority(&gstream, hipStreamNonBlocking, prio_hi_));
+      }
     }
     return 0;
   }
@@ -607,6 +616,7 @@ struct Eng : mdd_engine {
 #endif
     if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
     if (tside) { (void)hipStreamSynchronize(tside); (void)hipStreamDestroy(tside); }
+    if (gstream) { (void)hipStreamSynchronize(gstream); (void)hipStreamDestroy(gstream); }
     for (auto e : evs) (void)hipEventDestroy(e);
     for (auto& p : prof) { if (!p.shared_a) (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   }
@@ -651,6 +661,8 @@ struct Eng : mdd_engine {
   hipStream_t wstream(hipStream_t st) const { return use_side ? side : st; }
   const LinScratch& wlin() const { return use_side ? lin_side : lin_main; }
   hipStream_t tside = nullptr;   // text-projection stream
+  hipStream_t gstream = nullptr; // squeeze-excite gate chain of the forward passes (high queue priority: its small
+                                 // kernels take the next CU slots a conv3 block frees instead of queueing behind the grid)
   void fork_to(hipStream_t to, hipStream_t from) {
     if (to == from) return;
     order(to, from);
@@ -1019,17 +1031,32 @@ struct Eng : mdd_engine {
       conv_fwd(T, convs[B.c1], a, a_t, pa.C1, qa.C1, pa.A1, qa.A1, 1.f, th, th_t, st);
       conv_fwd(T, convs[B.c2], pa.A1, qa.A1, pa.C2, qa.C2, pa.A2, qa.A2, 1.f, th, th_t, st);
       conv_fwd(T, convs[B.c2b], pa.A2, qa.A2, pa.C2b, qa.C2b, pa.A2b, qa.A2b, 1.f, th, th_t, st);
-      conv_fwd(T, convs[B.c3], pa.A2b, qa.A2b, pa.C3, qa.C3, nullptr, nullptr, 1.f, th, th_t, st);
       int hw = B.hout * B.hout, c = B.se.c, rd = B.se.rd;
-      launch_pool_mean<AT>(T ? qa.p : pa.p, T ? qa.C3 : pa.C3, N, hw, c, st);
-      launch_linear_fwd(pa.h, T ? qa.h : nullptr, pa.p, T ? qa.p : nullptr, th + B.se.off_w1,
-                        T ? th_t + B.se.off_w1 : nullptr, th + B.se.off_b1,
-                        T ? th_t + B.se.off_b1 : nullptr, N, c, rd, 1, lin_main, st);
-      launch_linear_fwd(pa.gate, T ? qa.gate : nullptr, pa.h, T ? qa.h : nullptr, th + B.se.off_w2,
-                        T ? th_t + B.se.off_w2 : nullptr, th + B.se.off_b2,
-                        T ? th_t + B.se.off_b2 : nullptr, N, rd, c, 2, lin_main, st);
+      // Squeeze-excite gate.  conv3 is a pointwise (linear) conv, so the pooled conv3 output is conv3 applied to
+      // the pooled MID-channel activation: p = W3_hat q + b3 with q = mean_hw(A2b) -- a quarter of the bytes of
+      // pooling C3, and the whole gate chain (pool, three small-batch linears) no longer waits for conv3: it runs
+      // on the side stream beside it and meets the main stream at the SE apply.
+      bool g_forked = false;
+      {
+        hipStream_t gs = st;
+        if (use_side && MDD_SE_SIDE == 1) { fork(st); gs = side; sc_forked = true; }
+        if (use_side && MDD_SE_SIDE == 2 && gstream) { fork_to(gstream, st); gs = gstream; g_forked = true; }
+        const ConvL& L3 = convs[B.c3];
+        launch_pool_mean<AT>(T ? qa.q : pa.q, T ? qa.A2b : pa.A2b, N, hw, B.mid, gs);
+        launch_linear_fwd_w<AT>(pa.p, T ? qa.p : nullptr, pa.q, T ? qa.q : nullptr, wf + L3.off_p,
+                                T ? wf_t + L3.off_p : nullptr, th + L3.off_b, T ? th_t + L3.off_b : nullptr, N,
+                                B.mid, c, 1.f, gs);
+        launch_linear_fwd(pa.h, T ? qa.h : nullptr, pa.p, T ? qa.p : nullptr, th + B.se.off_w1,
+                          T ? th_t + B.se.off_w1 : nullptr, th + B.se.off_b1,
+                          T ? th_t + B.se.off_b1 : nullptr, N, c, rd, 1, lin_main, gs);
+        launch_linear_fwd(pa.gate, T ? qa.gate : nullptr, pa.h, T ? qa.h : nullptr, th + B.se.off_w2,
+                          T ? th_t + B.se.off_w2 : nullptr, th + B.se.off_b2,
+                          T ? th_t + B.se.off_b2 : nullptr, N, rd, c, 2, lin_main, gs);
+      }
+      conv_fwd(T, convs[B.c3], pa.A2b, qa.A2b, pa.C3, qa.C3, nullptr, nullptr, 1.f, th, th_t, st);
       bool lastb = b == nb - 1;
       if (sc_forked) join(st);
+      if (g_forked) join_from(gstream, st);
       launch_se_apply<AT>(pa.C3, T ? qa.C3 : nullptr, pa.gate, T ? qa.gate : nullptr, sc,
                           T ? sc_t : nullptr, P.X[b + 1], T ? Q.X[b + 1] : nullptr,
                           lastb ? nullptr : P.A[b + 1], (T && !lastb) ? Q.A[b + 1] : nullptr, ga,
@@ -1074,31 +1101,45 @@ struct Eng : mdd_engine {
       BlockActs& oa = O.blk[b];
       const AT *xb = O.XB[b + 1], *xb_t = Q.XB[b + 1];
       int hw = B.hout * B.hout, c = B.se.c, rd = B.se.rd;
-      // squeeze-excite backward
-      launch_se_gate_grad<AT>(oa.zB, T ? qa.zB : nullptr, xb, T ? xb_t : nullptr, pa.C3,
-                              T ? qa.C3 : nullptr, pa.gate, T ? qa.gate : nullptr, ga, N, hw, c, st);
-      launch_linear_dgrad(oa.hB, T ? qa.hB : nullptr, oa.zB, T ? qa.zB : nullptr,
-                          th + B.se.off_w2, T ? th_t + B.se.off_w2 : nullptr, pa.h, N, rd, c,
-                          lin_main, st);
+      // squeeze-excite backward.  One pass over (xb, C3) gives the gate gradient AND conv3's output gradient
+      // C3B = ga * gate * xb: with the pooled vector taken from the mid channels (img_forward) the pooled path's
+      // gradient no longer goes through C3 -- it reaches conv3's weights as the small outer product pb^T q, its
+      // bias as sum_n pb, and the residual branch as the per-image vector qb / hw added in conv3's data-gradient
+      // epilogue.
+      launch_se_gate_grad_c3b<AT>(oa.zB, T ? qa.zB : nullptr, oa.C3B, T ? qa.C3B : nullptr, xb, T ? xb_t : nullptr,
+                                  pa.C3, T ? qa.C3 : nullptr, pa.gate, T ? qa.gate : nullptr, ga, N, hw, c, st);
+      // conv3's weight gradient only needs C3B: release it (with what the previous block queued) now, so the
+      // side stream works while the main stream walks the small-batch chain below
+      conv_bwd_w(T, convs[B.c3], oa.C3B, qa.C3B, pa.A2b, qa.A2b, dw, dw_t, gout, st);
+      flush_w(st);
+      const ConvL& L3 = convs[B.c3];
       {
         const float *zB = oa.zB, *zB_t = T ? qa.zB : nullptr, *hh = pa.h, *hh_t = T ? qa.h : nullptr;
         const float *hB = oa.hB, *hB_t = T ? qa.hB : nullptr, *pp = pa.p, *pp_t = T ? qa.p : nullptr;
+        const float *pB = oa.pB, *pB_t = T ? qa.pB : nullptr, *qq = pa.q, *qq_t = T ? qa.q : nullptr;
         float *gw2 = gout + B.se.off_w2, *gb2 = gout + B.se.off_b2, *gw1 = gout + B.se.off_w1,
-              *gb1 = gout + B.se.off_b1;
-        const int n_ = N;
+              *gb1 = gout + B.se.off_b1, *gw3 = (T ? dw_t : dw) + L3.off_p, *gb3 = gout + L3.off_b;
+        const int n_ = N, mid_ = B.mid;
         wq.push_back([=](hipStream_t ws_) {
           launch_linear_wgrad(gw2, gb2, zB, zB_t, hh, hh_t, n_, rd, c, wlin(), ws_);
           launch_linear_wgrad(gw1, gb1, hB, hB_t, pp, pp_t, n_, c, rd, wlin(), ws_);
+          // after conv3's own weight gradient (queued above: same stream, in order) has overwritten its slice
+          launch_linear_wgrad_accum(gw3, gb3, pB, pB_t, qq, qq_t, n_, mid_, c, ws_);
         });
       }
+      launch_linear_dgrad(oa.hB, T ? qa.hB : nullptr, oa.zB, T ? qa.zB : nullptr,
+                          th + B.se.off_w2, T ? th_t + B.se.off_w2 : nullptr, pa.h, N, rd, c,
+                          lin_main, st);
       launch_linear_dgrad(oa.pB, T ? qa.pB : nullptr, oa.hB, T ? qa.hB : nullptr, th + B.se.off_w1,
                           T ? th_t + B.se.off_w1 : nullptr, nullptr, N, c, rd, lin_main, st);
-      launch_se_apply_bwd<AT>(oa.C3B, T ? qa.C3B : nullptr, xb, T ? xb_t : nullptr, pa.gate,
-                              T ? qa.gate : nullptr, oa.pB, T ? qa.pB : nullptr, ga, N, hw, c, st);
+      launch_linear_fwd_w<AT>(oa.qB, T ? qa.qB : nullptr, oa.pB, T ? qa.pB : nullptr, wt + L3.off_p,
+                              T ? wt_t + L3.off_p : nullptr, nullptr, nullptr, N, c, B.mid, 1.f, st);
       // residual branch
-      conv_bwd_w(T, convs[B.c3], oa.C3B, qa.C3B, pa.A2b, qa.A2b, dw, dw_t, gout, st);
-      conv_bwd_d(T, convs[B.c3], oa.C3B, qa.C3B,
-                 epi_act(T, oa.A2bB, oa.C2bB, qa.C2bB, pa.C2b, qa.C2b, 1.f, nullptr, nullptr), st);
+      {
+        ConvEpi e3 = epi_act(T, oa.A2bB, oa.C2bB, qa.C2bB, pa.C2b, qa.C2b, 1.f, nullptr, nullptr);
+        e3.ib = oa.qB; e3.ib_t = qa.qB; e3.ib_mul = 1.f / (float)hw; e3.ib_hw = hw;
+        conv_bwd_d(T, convs[B.c3], oa.C3B, qa.C3B, e3, st);
+      }
       conv_bwd_w(T, convs[B.c2b], oa.C2bB, qa.C2bB, pa.A2, qa.A2, dw, dw_t, gout, st);
       conv_bwd_d(T, convs[B.c2b], oa.C2bB, qa.C2bB,
                  epi_act(T, oa.A2B, oa.C2B, qa.C2B, pa.C2, qa.C2, 1.f, nullptr, nullptr), st);
@@ -1124,7 +1165,7 @@ struct Eng : mdd_engine {
       conv_bwd_d(T, convs[B.c1], oa.C1B, qa.C1B,
                  epi_act(T, oa.AinB, O.XB[b], Q.XB[b], P.X[b], Q.X[b], B.beta, add1,
                          B.ds >= 0 ? nullptr : (T ? xb_t : xb)), st);
-      if (b == 0 || (nb - 1 - b) % MDD_FLUSH_EVERY == MDD_FLUSH_EVERY - 1) flush_w(st);
+      if (b == 0) flush_w(st);
     }
     // stem (conv4 output is the raw stream X[0]; its grad is XB[0])
     conv_bwd_w(T, convs[stem[3]], O.XB[0], Q.XB[0], P.As[2], Q.As[2], dw, dw_t, gout, st);

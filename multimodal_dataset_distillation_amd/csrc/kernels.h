@@ -62,6 +62,12 @@ struct ConvEpi {
   const void* add1;       // AT*: added to the accumulator before anything else (or null)
   const void* add2;       // AT*: added to out_act result (or null)
   float beta;
+  // per-image bias of the pointwise data-gradient modes (EPI_BWD: ib, EPI_BWD_T: ib_t; ib non-null enables it):
+  // row m of the accumulator gets ib[m / ib_hw][channel] * ib_mul added before anything else
+  const float* ib;        // [nimg, co_tot] fp32 or null
+  const float* ib_t;
+  float ib_mul;
+  int ib_hw;
 };
 enum {
   EPI_FWD = 0,        // c = acc + bias ; out_raw = c ; out_act = beta*silu(c)
@@ -131,6 +137,12 @@ template <class AT>
 void launch_se_gate_grad(float* zbar, float* zbar_t, const AT* xbar, const AT* xbar_t,
                          const AT* c3, const AT* c3_t, const float* gate, const float* gate_t,
                          float ga, int n, int hw, int c, hipStream_t st);
+// the same reduction, and c3bar = xbar*gate*ga written in the same pass (the pooled path's gradient reaches the
+// residual branch through the mid-channel pooled vector: Eng::img_backward)
+template <class AT>
+void launch_se_gate_grad_c3b(float* zbar, float* zbar_t, AT* c3bar, AT* c3bar_t, const AT* xbar, const AT* xbar_t,
+                             const AT* c3, const AT* c3_t, const float* gate, const float* gate_t, float ga, int n,
+                             int hw, int c, hipStream_t st);
 // c3bar = xbar*gate*ga + pbar/hw
 template <class AT>
 void launch_se_apply_bwd(AT* c3bar, AT* c3bar_t, const AT* xbar, const AT* xbar_t,
@@ -153,6 +165,7 @@ constexpr int LIN_CTR_N = 256;
 struct LinScratch {
   float* part = nullptr; float* part_rs = nullptr; unsigned* ctr = nullptr;
   int64_t part_floats = 0, part_rs_floats = 0; int ctr_n = 0;
+  bool mfma = false;     // small-batch layer: route to the one-workgroup-per-tile matrix-core kernel (no scratch used)
 };
 int64_t lin_scratch_bytes();
 LinScratch lin_scratch_carve(void* base);
@@ -169,6 +182,14 @@ void launch_linear_dgrad(float* dx, float* dx_t, const float* dy, const float* d
 void launch_linear_wgrad(float* dW, float* db, const float* dy, const float* dy_t, const float* x,
                          const float* x_t, int n, int k, int j, const LinScratch& ws,
                          hipStream_t st);
+
+// y = alpha * (x W^T) + b with W [j,k] in the activation storage type (packed standardised conv weights)
+template <class TW>
+void launch_linear_fwd_w(float* y, float* y_t, const float* x, const float* x_t, const TW* W, const TW* W_t,
+                         const float* b, const float* b_t, int n, int k, int j, float alpha, hipStream_t st);
+// dW[j,k] += sum_n dy[n,j] x[n,k] ; db[j] += sum_n dy[n,j]  (accumulating form; db may be null)
+void launch_linear_wgrad_accum(float* dW, float* db, const float* dy, const float* dy_t, const float* x,
+                               const float* x_t, int n, int k, int j, hipStream_t st);
 
 // ---------------------------------------------------------------- retrieval.hip (fp32)
 // scores[b,n] = scale * <img_hat[i], txt_hat[j]> ; rank_i2t[i], rank_t2i[j] (see retrieval.hip).

@@ -251,12 +251,222 @@ __global__ __launch_bounds__(256, 4) void k_sgemm_small(const GArgs p) {
   }
 }
 
+
+// ====================================================================== small-batch linears on the matrix cores
+// One of the three GEMM dimensions is the number of synthetic pairs (10..500): the squeeze-excite MLPs, the
+// pooled-feature -> conv3 shortcut of the SE path and the text head.  These layers are latency, not
+// throughput: a [100 x 1536] x [1536 x 384] product is 0.12 GFLOP but sits in the dependent chain of every
+// residual block of every pass.  k_sgemm_small above split K over blocks and combined the partial tiles with
+// fp32 atomics + an arrival counter + an exchange: three dependent memory round trips per layer (20-30 us
+// beside the weight-gradient stream).  Here ONE workgroup owns a 16 x 16 output tile and splits K over its
+// NW waves (exact-fp32 v_mfma_f32_16x16x4_f32, operands straight from global memory into registers: every
+// lane loads 4 consecutive k of its row / column, the same k-permutation on both operands); the partial
+// accumulators meet in LDS, the epilogue (bias, activation or its tangent rule, ReLU mask, bias-gradient row
+// sums, accumulate-into) runs on the reduced tile, one store.  One memory round trip, no atomics, no scratch,
+// deterministic.  The B operand may be stored in bf16 (the packed standardised conv3 weights in bf16 mode).
+struct LArgs {
+  const float *A, *A_t;
+  const void *B, *B_t;
+  float* C;
+  int M, N, K;
+  int64_t sAm, sAk, sBn, sBk;   // element strides
+  int kw_len;                   // K range per wave (multiple of 8)
+  int vecA, vecB;               // 16-byte (8-byte for bf16) loads along k are legal
+  int epi, act, accum;
+  float alpha;
+  const float* bias;
+  const float* aux;
+  float* rowsum;
+};
+
+template <class TB> DEVI void ld4(const TB* p, float* o);
+template <> DEVI void ld4<float>(const float* p, float* o) {
+  const float4 v = *(const float4*)p; o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+template <> DEVI void ld4<bf16>(const bf16* p, float* o) {
+  const uint2 v = *(const uint2*)p;
+  o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+  o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+
+// Register diet on purpose: these layers run beside the weight-gradient contractions (2 blocks of 188 registers per
+// CU leave 136 per SIMD lane) -- a wave that needs more waits for a whole contraction block to retire (50-90 us).
+template <int NW, int MODE, class TB, bool AKC, bool BKC>
+__global__ __launch_bounds__(NW * 64, NW >= 4 ? 4 : (NW == 2 ? 4 : 4)) void k_lin_mfma(const LArgs p) {
+  // 16 x 16 output tile per workgroup, v_mfma_f32_16x16x4_f32: lane = (r = lane & 15, kq = lane >> 4) supplies
+  // A[row r][k] / B[col r][k] for k = 16 s + 4 kq + j (one 16-byte load per operand and step s, four MFMAs j = 0..3
+  // -- the same k-permutation on both operands); the four lanes of a row read 64 contiguous bytes per load.
+  __shared__ float red[NW][4][64];
+  __shared__ float rsum[NW][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+  const int row = min(m0 + l15, p.M - 1), col = min(n0 + l15, p.N - 1);   // clamped: never stored
+  const int k0 = wave * p.kw_len, k1 = min(p.K, k0 + p.kw_len);
+  const bool hasAt = MODE && p.A_t != nullptr, hasBt = MODE && p.B_t != nullptr;
+  const bool do_rs = p.rowsum != nullptr && blockIdx.x == 0;
+  const float* Ar = p.A + (AKC ? (int64_t)row * p.sAm : (int64_t)row);
+  const float* Atr = hasAt ? p.A_t + (AKC ? (int64_t)row * p.sAm : (int64_t)row) : nullptr;
+  const TB* Br = (const TB*)p.B + (BKC ? (int64_t)col * p.sBn : (int64_t)col);
+  const TB* Btr = hasBt ? (const TB*)p.B_t + (BKC ? (int64_t)col * p.sBn : (int64_t)col) : nullptr;
+
+  constexpr int U = 2;                 // steps (of 16 k) per register chunk (two chunks in flight)
+  struct Frag { float a[U][4], b[U][4], at[MODE ? U : 1][4], bt[MODE ? U : 1][4]; };
+  auto ldA = [&](const float* P, int kk, float* o) __attribute__((always_inline)) {
+    if constexpr (AKC) {
+      if (kk < k1) {
+        if (p.vecA) ld4<float>(P + kk, o);
+        else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] = (kk + i < k1) ? P[kk + i] : 0.f;
+        }
+      } else { o[0] = o[1] = o[2] = o[3] = 0.f; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = (kk + i < k1) ? P[(int64_t)(kk + i) * p.sAk] : 0.f;
+    }
+  };
+  auto ldB = [&](const TB* P, int kk, float* o) __attribute__((always_inline)) {
+    if constexpr (BKC) {
+      if (kk < k1) {
+        if (p.vecB) ld4<TB>(P + kk, o);
+        else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] = (kk + i < k1) ? to_f(P[kk + i]) : 0.f;
+        }
+      } else { o[0] = o[1] = o[2] = o[3] = 0.f; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = (kk + i < k1) ? to_f(P[(int64_t)(kk + i) * p.sBk]) : 0.f;
+    }
+  };
+  auto load = [&](Frag& f, int kc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kk = kc + 16 * u + 4 * kq;
+      ldA(Ar, kk, f.a[u]);
+      ldB(Br, kk, f.b[u]);
+      if constexpr (MODE != 0) {
+        if (hasAt) ldA(Atr, kk, f.at[u]); else { f.at[u][0] = f.at[u][1] = f.at[u][2] = f.at[u][3] = 0.f; }
+        if (hasBt) ldB(Btr, kk, f.bt[u]); else { f.bt[u][0] = f.bt[u][1] = f.bt[u][2] = f.bt[u][3] = 0.f; }
+      }
+    }
+  };
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float rs = 0.f;
+  Frag cur, nxt;
+  if (k0 < k1) load(cur, k0);
+  for (int kc = k0; kc < k1; kc += 16 * U) {
+    const bool more = kc + 16 * U < k1;
+    if (more) load(nxt, kc + 16 * U);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (MODE == 0) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[u][i], cur.b[u][i], acc, 0, 0, 0);
+          if (do_rs) rs += cur.a[u][i];
+        } else {
+          if (hasAt) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.at[u][i], cur.b[u][i], acc, 0, 0, 0);
+          if (hasBt) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[u][i], cur.bt[u][i], acc, 0, 0, 0);
+          if (do_rs) rs += cur.at[u][i];
+        }
+      }
+    }
+    if (more) cur = nxt;
+  }
+  // ---- the NW partial tiles meet in LDS (C/D map of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + r)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc[r];
+  if (do_rs) {
+    rs += __shfl_xor(rs, 16, 64);
+    rs += __shfl_xor(rs, 32, 64);
+    if (kq == 0) rsum[wave][l15] = rs;
+  }
+  __syncthreads();
+  if (do_rs && tid < 16 && m0 + tid < p.M) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += rsum[w][tid];
+    p.rowsum[m0 + tid] = p.accum ? p.rowsum[m0 + tid] + s : s;
+  }
+  const int n = n0 + l15;
+  // 256 outputs: thread (wave w, lane) takes accumulator register r = w (+ NW, ...) of every wave's tile
+  for (int r = wave; r < 4; r += NW) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += red[w][r][lane];
+    const int m = m0 + 4 * kq + r;
+    if (m >= p.M || n >= p.N) continue;
+    v *= p.alpha;
+    const int64_t ci = (int64_t)m * p.N + n;
+    if (p.epi == EP_BIAS_ACT) {
+      v += p.bias ? p.bias[n] : 0.f;
+      if (p.act == 1) v = relu_(v);
+      else if (p.act == 2) v = sigmoid_(v);
+    } else if (p.epi == EP_BIAS_ACT_T) {
+      v += p.bias ? p.bias[n] : 0.f;
+      const float yv = p.aux ? p.aux[ci] : 0.f;
+      v *= p.act == 1 ? (yv > 0.f ? 1.f : 0.f) : (p.act == 2 ? yv * (1.f - yv) : 1.f);
+    } else if (p.epi == EP_RELU_MASK) {
+      v = p.aux[ci] > 0.f ? v : 0.f;
+    }
+    if (p.accum) v += p.C[ci];
+    p.C[ci] = v;
+  }
+}
+
+template <int NW, int MODE, class TB>
+void lin_mfma_launch(const LArgs& a, dim3 grid, hipStream_t st) {
+  const bool akc = a.sAk == 1, bkc = a.sBk == 1;
+  if (akc && bkc) k_lin_mfma<NW, MODE, TB, true, true><<<grid, NW * 64, 0, st>>>(a);
+  else if (akc) k_lin_mfma<NW, MODE, TB, true, false><<<grid, NW * 64, 0, st>>>(a);
+  else if (bkc) k_lin_mfma<NW, MODE, TB, false, true><<<grid, NW * 64, 0, st>>>(a);
+  else k_lin_mfma<NW, MODE, TB, false, false><<<grid, NW * 64, 0, st>>>(a);
+}
+
+// C[M,N] (+)= alpha * sum_k A[m,k] B[n,k]  (tangent: A_t B + A B_t), epilogue as in run_gemm
+template <class TB>
+void run_lin_mfma(bool tangent, const float* A, const float* A_t, const TB* B, const TB* B_t, float* C, int M,
+                  int N, int K, int64_t sAm, int64_t sAk, int64_t sBk, int64_t sBn, int epi, int act,
+                  const float* bias, const float* aux, float* rowsum, int accum, float alpha, hipStream_t st) {
+  LArgs a;
+  a.A = A; a.A_t = A_t; a.B = B; a.B_t = B_t; a.C = C; a.M = M; a.N = N; a.K = K;
+  a.sAm = sAm; a.sAk = sAk; a.sBn = sBn; a.sBk = sBk;
+  a.epi = epi; a.act = act; a.accum = accum; a.alpha = alpha; a.bias = bias; a.aux = aux; a.rowsum = rowsum;
+  auto al = [](const void* q, size_t b) { return q == nullptr || ((uintptr_t)q & (b - 1)) == 0; };
+  a.vecA = sAk == 1 && al(A, 16) && al(A_t, 16) && sAm % 4 == 0 && K % 4 == 0;
+  a.vecB = sBk == 1 && al(B, 4 * sizeof(TB)) && al(B_t, 4 * sizeof(TB)) && sBn % 4 == 0 && K % 4 == 0;
+  const int tiles = ((M + 15) / 16) * ((N + 15) / 16);
+  // waves per tile: fill the 1024 SIMDs about twice, at least 64 k per wave, at most 8 waves
+  int nw = 1;
+  while (nw < 8 && tiles * nw < 2048 && K / (nw * 2) >= 64) nw *= 2;
+  a.kw_len = ((K + nw - 1) / nw + 15) / 16 * 16;
+  dim3 grid((N + 15) / 16, (M + 15) / 16, 1);
+#define LIN_GO(NWV)                                                      \
+  do {                                                                   \
+    if (tangent) lin_mfma_launch<NWV, 1, TB>(a, grid, st);               \
+    else lin_mfma_launch<NWV, 0, TB>(a, grid, st);                       \
+  } while (0)
+  switch (nw) {
+    case 1: LIN_GO(1); break;
+    case 2: LIN_GO(2); break;
+    case 4: LIN_GO(4); break;
+    default: LIN_GO(8); break;
+  }
+#undef LIN_GO
+}
+
 inline bool al16(const void* p) { return p == nullptr || ((uintptr_t)p & 15) == 0; }
 
 void run_gemm(bool tangent, const float* A, const float* A_t, const float* B, const float* B_t,
               float* C, int M, int N, int K, int64_t sAm, int64_t sAk, int64_t sBk, int64_t sBn,
               int epi, int act, const float* bias, const float* aux, float* rowsum,
               const LinScratch& ws, hipStream_t st) {
+  if (ws.mfma) {   // small-batch layer: one workgroup per 32x32 tile on the matrix cores, no split-K scratch
+    run_lin_mfma<float>(tangent, A, A_t, B, B_t, C, M, N, K, sAm, sAk, sBk, sBn, epi, act, bias, aux, rowsum, 0,
+                        1.f, st);
+    return;
+  }
   GArgs g;
   g.A = A; g.A_t = A_t; g.B = B; g.B_t = B_t; g.C = C; g.M = M; g.N = N; g.K = K;
   g.sAm = sAm; g.sAk = sAk; g.sBk = sBk; g.sBn = sBn;
@@ -298,6 +508,7 @@ LinScratch lin_scratch_carve(void* base) {
   s.part = (float*)base; s.part_floats = LIN_PART_FLOATS;
   s.part_rs = s.part + LIN_PART_FLOATS; s.part_rs_floats = LIN_PART_RS_FLOATS;
   s.ctr = (unsigned*)(s.part_rs + LIN_PART_RS_FLOATS); s.ctr_n = LIN_CTR_N;
+  s.mfma = true;
   return s;
 }
 
@@ -323,4 +534,26 @@ void launch_linear_wgrad(float* dW, float* db, const float* dy, const float* dy_
   bool tangent = dy_t || x_t;
   if (tangent) run_gemm(true, dy, dy_t, x, x_t, dW, j, k, n, 1, j, k, 1, EP_PLAIN, 0, nullptr, nullptr, db, ws, st);
   else run_gemm(false, dy, nullptr, x, nullptr, dW, j, k, n, 1, j, k, 1, EP_PLAIN, 0, nullptr, nullptr, db, ws, st);
+}
+
+// ---- typed-weight forms (W in the activation storage type: the packed standardised conv weights)
+// y[n,j] = sum_k x[n,k] W[j,k] + b[j]   (tangent: x_t W + x W_t + b_t, written to y_t)
+template <class TW>
+void launch_linear_fwd_w(float* y, float* y_t, const float* x, const float* x_t, const TW* W, const TW* W_t,
+                         const float* b, const float* b_t, int n, int k, int j, float alpha, hipStream_t st) {
+  if (y_t) run_lin_mfma<TW>(true, x, x_t, W, W_t, y_t, n, j, k, k, 1, 1, k, EP_BIAS_ACT_T, 0, b_t, nullptr, nullptr,
+                            0, alpha, st);
+  else run_lin_mfma<TW>(false, x, nullptr, W, nullptr, y, n, j, k, k, 1, 1, k, EP_BIAS_ACT, 0, b, nullptr, nullptr, 0,
+                        alpha, st);
+}
+template void launch_linear_fwd_w<float>(float*, float*, const float*, const float*, const float*, const float*,
+                                         const float*, const float*, int, int, int, float, hipStream_t);
+template void launch_linear_fwd_w<bf16>(float*, float*, const float*, const float*, const bf16*, const bf16*,
+                                        const float*, const float*, int, int, int, float, hipStream_t);
+// dW[j,k] += sum_n dy[n,j] x[n,k] ; db[j] += sum_n dy[n,j]   (tangent: dy_t x + dy x_t ; db += sum dy_t)
+void launch_linear_wgrad_accum(float* dW, float* db, const float* dy, const float* dy_t, const float* x,
+                               const float* x_t, int n, int k, int j, hipStream_t st) {
+  const bool tangent = dy_t || x_t;
+  run_lin_mfma<float>(tangent, dy, dy_t, x, x_t, dW, j, k, n, 1, j, k, 1, EP_PLAIN, 0, nullptr, nullptr, db, 1, 1.f,
+                      st);
 }

@@ -268,10 +268,15 @@ def main(args):
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
+        # Evaluation (every --eval_it iterations) runs on rank 0 while the other ranks already wait in the
+        # iteration's all-reduce: the process-group timeout must cover a whole evaluate_synset sweep
+        # (num_eval x (epoch_eval_train + 1) epochs), not the 10-minute default.
+        import datetime
+        tmo = datetime.timedelta(minutes=float(os.environ.get("DISTILL_DIST_TIMEOUT_MIN", "240")))
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # RCCL over xGMI
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=tmo)   # RCCL over xGMI
         else:
-            dist.init_process_group(args.dist_backend)   # gloo: several ranks sharing one GPU (tests)
+            dist.init_process_group(args.dist_backend, timeout=tmo)   # gloo: several ranks sharing one GPU (tests)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     args.device = str(device)
@@ -280,7 +285,13 @@ def main(args):
     # with --distributed: mode B = the reference flag's meaning (nn.DataParallel, distill.py:443-445):
     # every rank a chunk of each minibatch, SAME expert / start epoch / permutations everywhere
     mode_b = bool(args.distributed) and world > 1
-    np.random.seed(args.seed + (0 if mode_b else rank))
+    # The synthetic set is REPLICATED in both modes: its initial draw (real pairs: np.random.permutation inside
+    # get_images_texts, reference distill.py:97-105) must be the same on every rank, so numpy is seeded with the
+    # bare seed until the set exists and only then per rank (mode A: every rank its own start epochs).
+    np.random.seed(args.seed)
+    stray = _lib.stray_env()
+    if stray and rank == 0:
+        print("note: MDD_* environment variables are set and ignored by the product library:", stray)
     if args.image_encoder not in VARIANTS:
         raise NotImplementedError("hot path encoders: %s" % sorted(VARIANTS))
     variant = VARIANTS[args.image_encoder]
@@ -314,6 +325,9 @@ def main(args):
         eval_set = (ti.to(device).contiguous(), te.to(device).contiguous(), i2t, t2i)
     eval_it_pool = set(np.arange(0, args.Iteration + 1, max(1, args.eval_it)).tolist())
     image_syn, text_syn = init_synthetic_set(args, d_txt, device, train_caption_embed)
+    if world > 1:      # one synthetic set, whatever a rank's RNG state was: rank 0's draw wins
+        dist.broadcast(image_syn, 0), dist.broadcast(text_syn, 0)
+    np.random.seed(args.seed + (0 if mode_b else rank))
     if train_sentences is not None and rank == 0:      # distill.py:244: decode of the initial text_syn
         sl = nearest_neighbor(train_sentences, text_syn, train_caption_embed, device=device)
         print("original_sentence_list:", " | ".join(sl[:5]), "..." if len(sl) > 5 else "")
@@ -440,6 +454,8 @@ def main(args):
     if nan_at is not None:
         print("img_param_loss is NaN at iteration %d: stopping (reference distill.py:599); the synthetic set "
               "is the one before that iteration's update" % nan_at)
+    if coll is not None:
+        coll.close()      # ncclCommDestroy before torch's own process group goes away
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -299,6 +299,10 @@ def main():
     if "c2s" in which:  # BASELINE config 2's spatial scale (N=100 @224, NFNet-l0), one unrolled step
         gen_unroll(ReparamModule, RefHead, os.path.join(out, "unroll_c2s_scalars.npz"), "nfnet_l0",
                    n=100, size=224, d_txt=768, K=1, outer_its=1, full=False, seed=300, cross_check=False)
+    if "k8" in which:  # BASELINE config 2's unroll depth on the full-width encoder: syn_steps=8, N=12 @224 (the same
+        # number of image-steps in the double-backward graph as the N=100 x K=1 fixture)
+        gen_unroll(ReparamModule, RefHead, os.path.join(out, "unroll_k8_scalars.npz"), "nfnet_l0",
+                   n=12, size=224, d_txt=768, K=8, outer_its=1, full=False, seed=400, cross_check=False)
     if "c1" in which:  # BASELINE config 1: N=10, syn_steps=2, NFNet-l0 + 768-d text, fp32 CPU
         gen_unroll(ReparamModule, RefHead, os.path.join(out, "unroll_c1_scalars.npz"), "nfnet_l0",
                    n=10, size=224, d_txt=768, K=2, outer_its=1, full=False, seed=200)

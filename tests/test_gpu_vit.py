@@ -94,6 +94,10 @@ def _case(variant, nq, batch, size, d_txt, K, seed):
 @pytest.mark.parametrize("variant,nq,batch,size,d_txt,K", [
     ("vit_micro", 6, 4, 32, 16, 3),        # 17 tokens, minibatch subsets that overlap between steps
     ("vit_micro", 3, 3, 64, 24, 2),        # 65 tokens: more than one 64-row tile per attention matrix
+    # the REAL geometries against the live oracle: 197 = 3 x 64 + 5 tokens in the 64 x 64 attention
+    # tiles, head dim 64, the 3- / 12-head slicing of the fused qkv tensor, the 196-patch embedding at patch 16
+    ("vit_tiny16", 3, 3, 224, 32, 2),      # timm vit_tiny_patch16_224 (reference networks.py:668), two unrolled steps
+    ("vit_b16", 2, 2, 224, 32, 1),         # BASELINE configs[4]'s encoder
 ])
 def test_vit_outer_iteration_matches_the_oracle(variant, nq, batch, size, d_txt, K, report):
     from multimodal_dataset_distillation_amd.engine import UnrollEngine
