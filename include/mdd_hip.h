@@ -65,9 +65,9 @@ typedef struct mdd_config {
 
 const char* mdd_last_error(void);
 /* ABI version of this header: 2 = round 2 (mdd_config.keep_steps, MDD_DTYPE_BF16X2 / _F32_BF16OPS,
- * profile kind 4); 3 = + mdd_comm_* / mdd_allreduce_syn_grads; 4 = + the ViT building-block ops.  A binding built against another version
+ * profile kind 4); 3 = + mdd_comm_* / mdd_allreduce_syn_grads; 4 = + the ViT building-block ops; 5 = + mdd_engine_set_pass_precision.  A binding built against another version
  * must refuse to load. */
-#define MDD_ABI_VERSION 4
+#define MDD_ABI_VERSION 5
 int mdd_version(void);
 
 /* ---- engine lifetime and memory (the caller owns device memory: PyTorch caching allocator) */
@@ -180,6 +180,11 @@ int mdd_unrolled_match(mdd_engine* e, const mdd_iter_args* a, void* stream);
  * contraction kernel alone), 4 = the split-M reduce kernel that follows each conv_wgrad.
  * out4 = {launches, total milliseconds, algorithmic FLOPs, algorithmic bytes} since enable. */
 int mdd_engine_profile(mdd_engine* e, int enable);
+/* fp32-storage engines (MDD_DTYPE_F32 / _BF16X2 / _F32_BF16OPS): operand arithmetic of the image encoder's
+ * contractions per pass -- F (reference distill.py:524), B (:562-567), T-F and T-B (what :606 differentiates):
+ * 0 = the engine's own mode, 1 = split-bf16 (hi + lo), 2 = one bf16 per operand, 3 = exact fp32 MFMA.  Used for the
+ * per-pass error attribution and for mixed parity-grade modes. */
+int mdd_engine_set_pass_precision(mdd_engine* e, int fwd, int bwd, int tan_fwd, int tan_bwd);
 int mdd_engine_profile_read(mdd_engine* e, int kind, double* out4);
 /* one CSV row per contraction launch since enable (geometry, ms, TFLOP/s, GB/s) */
 int mdd_engine_profile_dump(mdd_engine* e, const char* path);

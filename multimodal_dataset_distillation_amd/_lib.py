@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmdd_hip.so")
 
 DTYPE_F32, DTYPE_BF16, DTYPE_BF16X2, DTYPE_F32_BF16OPS = 0, 1, 2, 3
-ABI_VERSION = 4     # include/mdd_hip.h MDD_ABI_VERSION
+ABI_VERSION = 5     # include/mdd_hip.h MDD_ABI_VERSION
 
 
 class MddConfig(C.Structure):
@@ -60,6 +60,7 @@ SIGNATURES = {
     "mdd_flat_sgd_momentum": (_I, [_P, _P, _P, _F, _F, _I, _L, _P]),
     "mdd_flat_sgd_momentum_guarded": (_I, [_P, _P, _P, _F, _F, _I, _L, _P, _P]),
     "mdd_engine_profile": (_I, [_P, _I]),
+    "mdd_engine_set_pass_precision": (_I, [_P, _I, _I, _I, _I]),
     "mdd_engine_profile_read": (_I, [_P, _I, C.POINTER(C.c_double)]),
     "mdd_engine_profile_dump": (_I, [_P, C.c_char_p]),
     "mdd_unrolled_match": (_I, [_P, C.POINTER(MddIterArgs), _P]),

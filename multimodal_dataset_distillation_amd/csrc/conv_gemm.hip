@@ -53,7 +53,7 @@ template <> struct Mma<bf16> {
   static constexpr int KE = 64;  // K elements per 128-byte row
   static constexpr int CE = 8;   // elements per 16-byte chunk
   static DEVI u32x4 stage(const u32x4& raw, bool) { return raw; }
-  static DEVI void step(const u32x4& a, const u32x4& b, f32x16& acc) {
+  static DEVI void step(const u32x4& a, const u32x4& b, f32x16& acc, bool = false) {
     bf16x8 av = __builtin_bit_cast(bf16x8, a), bv = __builtin_bit_cast(bf16x8, b);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
   }
@@ -62,7 +62,7 @@ template <> struct Mma<float> {
   static constexpr int KE = 32;
   static constexpr int CE = 4;
   static DEVI u32x4 stage(const u32x4& raw, bool) { return raw; }
-  static DEVI void step(const u32x4& a, const u32x4& b, f32x16& acc) {
+  static DEVI void step(const u32x4& a, const u32x4& b, f32x16& acc, bool = false) {
     // lane-half h holds k = 4*(2q+h)+j, j=0..3 for BOTH operands: any k-permutation that is the
     // same for A and B leaves the sum unchanged.
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[0]), __uint_as_float(b[0]), acc, 0, 0, 0);
@@ -99,17 +99,19 @@ struct MmaSplit {
     o[2] = l[0] | (l[1] << 16); o[3] = l[2] | (l[3] << 16);
     return o;
   }
-  static DEVI void step(const u32x4& a, const u32x4& b, f32x16& acc) {
+  // hi: the lo halves are zero (one-bf16-per-operand passes of a mixed mode): hh is the whole product
+  static DEVI void step(const u32x4& a, const u32x4& b, f32x16& acc, bool hi = false) {
     u32x4 bs;
     bs[0] = b[2]; bs[1] = b[3]; bs[2] = b[0]; bs[3] = b[1];
     bf16x8 av = __builtin_bit_cast(bf16x8, a);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, bs), acc, 0, 0, 0);
+    if (!hi) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, bs), acc, 0, 0, 0);
   }
   // Two chunks of each operand at once (eight K positions per lane): regrouping their registers as
   // [h0..h7] and [l0..l7] costs no instruction and lets the ll term (below 2^-16 relative) be dropped:
   // hh + hl + lh = three MFMAs per eight K positions instead of four.
-  static DEVI void step2(const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1, f32x16& acc) {
+  static DEVI void step2(const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1, f32x16& acc,
+                         bool hi = false) {
     u32x4 ah, al, bh, bl;
     ah[0] = a0[0]; ah[1] = a0[1]; ah[2] = a1[0]; ah[3] = a1[1];
     al[0] = a0[2]; al[1] = a0[3]; al[2] = a1[2]; al[3] = a1[3];
@@ -117,6 +119,7 @@ struct MmaSplit {
     bl[0] = b0[2]; bl[1] = b0[3]; bl[2] = b1[2]; bl[3] = b1[3];
     const bf16x8 ahv = __builtin_bit_cast(bf16x8, ah), bhv = __builtin_bit_cast(bf16x8, bh);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahv, bhv, acc, 0, 0, 0);
+    if (hi) return;
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahv, __builtin_bit_cast(bf16x8, bl), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), bhv, acc, 0, 0, 0);
   }
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) MT::step(af[i], bf[j], acc[i][j]);
+            for (int j = 0; j < TN; ++j) MT::step(af[i], bf[j], acc[i][j], hi_only);
         }
       }
     } else
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) MT::step(af[q & 1][i], bf[q & 1][j], acc[i][j]);
+        for (int j = 0; j < TN; ++j) MT::step(af[q & 1][i], bf[q & 1][j], acc[i][j], hi_only);
       __builtin_amdgcn_sched_barrier(0);
     }
     } else if constexpr (PREC == 1 && MDD_SPLIT_3TERM && WGM == 2) {
@@ -490,7 +493,7 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) MT::step2(af[0][i], af[1][i], bf[0][j], bf[1][j], acc[i][j]);
+        for (int j = 0; j < TN; ++j) MT::step2(af[0][i], af[1][i], bf[0][j], bf[1][j], acc[i][j], hi_only);
     }
     } else {
 #pragma unroll
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) MT::step(af[i], bf[j], acc[i][j]);
+        for (int j = 0; j < TN; ++j) MT::step(af[i], bf[j], acc[i][j], hi_only);
     }
     }
 #pragma unroll

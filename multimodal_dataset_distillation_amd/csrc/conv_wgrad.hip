@@ -318,8 +318,10 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
             bf16x8 b8h = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(bh[j][0], bh[j][1], 0, 1, 2, 3, 4, 5, 6, 7));
             bf16x8 b8l = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(bl[j][0], bl[j][1], 0, 1, 2, 3, 4, 5, 6, 7));
             accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8h, a8h, accb[i][j], 0, 0, 0);
-            accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8l, a8h, accb[i][j], 0, 0, 0);
-            accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8h, a8l, accb[i][j], 0, 0, 0);
+            if (!hi_only) {    // one-bf16-per-operand passes of a mixed mode: the lo planes are zero
+              accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8l, a8h, accb[i][j], 0, 0, 0);
+              accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8h, a8l, accb[i][j], 0, 0, 0);
+            }
           }
       }
     } else if constexpr (!BF) {
@@ -479,7 +481,11 @@ void launch_cfg(WArgs a, float* slab, int64_t slab_floats, hipEvent_t ev_mid, hi
   const int nsrc = a.dy2 ? 2 : 1;
   const int64_t out_floats = (int64_t)g.groups * g.nc * ktot;
   const double out_mb = (double)out_floats * 4.0 / 1e6;
-  const bool two_phase = slab != nullptr && slab_floats >= out_floats;
+  // the split-M reduce kernel moves float4 columns into dW: it needs a whole number of them and a 16-byte aligned
+  // destination, otherwise the combine falls back to fp32 atomics (the caller then provides a zeroed dW: the
+  // single-op entry point and the ViT linears, whose dW is a slice of the zeroed flat gradient)
+  const bool two_phase = slab != nullptr && slab_floats >= out_floats && out_floats % 4 == 0 &&
+                         ((uintptr_t)a.dW & 15) == 0;
   // cost of combining one more split: atomics ~1.3 TB/s of added bytes; slabs: one streamed write + one
   // streamed read of the partial tile (~5 TB/s each)
   const double comb_us_per_mb = two_phase ? 0.6 : 1.0 / 1.3;

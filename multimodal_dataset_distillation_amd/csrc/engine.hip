@@ -90,11 +90,14 @@ bool get_cfg(const char* variant, NfCfg& c) {
 }
 
 // ViT topology (BASELINE configs[4]; timm 0.6.7 VisionTransformer as restated in oracle/vit_ref.py)
-struct VitCfg { int patch, dim, depth, heads; float eps; };
+struct VitCfg { int patch, dim, depth, heads; float eps; int head = 0; };   // head > 0: classifier Linear(dim, head)
 bool get_vit_cfg(const char* variant, VitCfg& c) {
   if (!strcmp(variant, "vit_b16")) { c = {16, 768, 12, 12, 1e-6f}; return true; }      // vit_base_patch16_224
   if (!strcmp(variant, "vit_tiny16")) { c = {16, 192, 12, 3, 1e-6f}; return true; }    // vit_tiny_patch16_224 (networks.py:668)
   if (!strcmp(variant, "vit_micro")) { c = {8, 64, 2, 2, 1e-6f}; return true; }        // build-defined miniature (tests)
+  // the reference's 'vit' as it stands (networks.py:668: no num_classes=0): timm's 1000-way head stays on the model
+  if (!strcmp(variant, "vit_tiny16_cls")) { c = {16, 192, 12, 3, 1e-6f, 1000}; return true; }
+  if (!strcmp(variant, "vit_micro_cls")) { c = {8, 64, 2, 2, 1e-6f, 24}; return true; }
   return false;
 }
 
@@ -152,6 +155,7 @@ struct mdd_engine {
                           const float* y_t, const float* scale_dev, float scale_const, float* loss,
                           float* xbar, float* ybar, float* sbar, hipStream_t st) = 0;
   virtual int unrolled_match(const mdd_iter_args* a, hipStream_t st) = 0;
+  virtual int set_pass_prec(const int* q4) = 0;
   virtual void profile_enable(bool on) = 0;
   virtual int profile_read(int kind, double* out4) = 0;
   virtual int profile_dump(const char* path) = 0;
@@ -171,8 +175,24 @@ struct Eng : mdd_engine {
   int Tk = 0, sld = 0;     // tokens per image (1 + patches), row stride of the score / probability matrices
   std::vector<VitBlkL> vblk;
   int pe_conv = -1;
-  int64_t off_cls = 0, off_pos = 0, off_nw = 0, off_nb = 0;
+  int64_t off_cls = 0, off_pos = 0, off_nw = 0, off_nb = 0, off_hw = 0, off_hb = 0;
   int prec = 0;   // ConvGeom::prec of every contraction (fp32 storage: 0 exact, 1 split-bf16, 2 hi only)
+  // fp32-storage engines: operand arithmetic of the image encoder's contractions per pass {F, B, T-F, T-B}
+  // (0 = the engine's mode; mdd_engine_set_pass_precision -- the attribution table of DESIGN.md section 5)
+  int pass_prec[4] = {0, 0, 0, 0};
+  int cur_prec = 0;
+  void select_prec(bool T, bool bwd) {
+    const int q = pass_prec[(T ? 2 : 0) + (bwd ? 1 : 0)];
+    cur_prec = (sizeof(AT) == 4 && q != 0) ? (q == 3 ? 0 : q) : prec;
+  }
+  int set_pass_prec(const int* q) override {
+    for (int i = 0; i < 4; ++i) {
+      CHECK_ARG(q[i] >= 0 && q[i] <= 3, "pass precision must be 0 (engine mode), 1 (split bf16), 2 (one bf16), 3 (exact fp32)");
+      pass_prec[i] = q[i];
+    }
+    CHECK_ARG(sizeof(AT) == 4 || (q[0] | q[1] | q[2] | q[3]) == 0, "per-pass precision needs an fp32-storage engine");
+    return 0;
+  }
   int N, S, Dt, K;
   // Activation stash policy: steps k < keep own stash slot k; steps k >= keep share slot
   // `keep` and are recomputed by the reverse sweep.  nslots = activation sets besides the tangent set.
@@ -204,6 +224,7 @@ struct Eng : mdd_engine {
   struct ActSet {
     AT *VCOL = nullptr, *VPE = nullptr, *VCOLB = nullptr, *VPEB = nullptr;   // patch columns, patch embedding (+ grads)
     AT *CLS = nullptr, *CLSN = nullptr, *CLSNB = nullptr, *CLSB = nullptr, *TMP = nullptr;
+    float *hin = nullptr, *hinB = nullptr;     // fp32 copies of the normalised class token / its gradient (classifier head)
     std::vector<VitActs> vb;
     AT* X0;
     AT *Cs[3], *As[3];
@@ -313,10 +334,13 @@ struct Eng : mdd_engine {
         vblk.push_back(B);
       }
       off_nw = add_param(pimg, "model.norm.weight", {D}); off_nb = add_param(pimg, "model.norm.bias", {D});
+      if (vit.head > 0) {
+        off_hw = add_param(pimg, "model.head.weight", {vit.head, D}); off_hb = add_param(pimg, "model.head.bias", {vit.head});
+      }
       int ce = 16 / (int)sizeof(AT);
       CHECK_ARG(D % ce == 0 && (3 * vit.patch * vit.patch) % ce == 0 && (D / vit.heads) % 4 == 0,
                 "dims must be multiples of the 16-byte chunk");
-      P_img = off; feat = D;
+      P_img = off; feat = vit.head > 0 ? vit.head : D;
       stem[0] = stem[1] = stem[2] = stem[3] = fin = -1;
       for (auto& L : convs) {
         LinPackDesc d; d.off_w = L.off_w; d.off_p = L.off_p; d.out = L.cout; d.in = L.cin; d.tile_start = lpd_tiles; d.pad_ = 0;
@@ -407,6 +431,7 @@ struct Eng : mdd_engine {
     plan(&s.CLS, n * D, "vit.CLS", slot); plan(&s.CLSN, n * D, "vit.CLSN", slot);
     plan(&s.CLSNB, n * D, "vit.CLSNB", slot); plan(&s.CLSB, n * D, "vit.CLSB", slot);
     plan(&s.TMP, M * D, "vit.TMP", slot);
+    plan(&s.hin, n * D, "vit.hin", slot); plan(&s.hinB, n * D, "vit.hinB", slot);
     s.X.resize(vit.depth + 1); s.XB.resize(vit.depth + 1); s.vb.resize(vit.depth);
     for (int l = 0; l <= vit.depth; ++l) {
       plan(&s.X[l], M * D, ("X" + std::to_string(l)).c_str(), slot);
@@ -597,13 +622,13 @@ struct Eng : mdd_engine {
     ConvGeom g; g.nimg = L.tokens ? N * L.tokens : N; g.ha = L.hin; g.wa = L.hin; g.ca_tot = L.cin_pad;
     g.ho = L.hout; g.wo = L.hout; g.co_tot = L.cout; g.kc = L.cin_pad / L.groups;
     g.nc = L.cout / L.groups; g.groups = L.groups; g.k = L.k; g.stride = L.stride; g.pad = L.pad;
-    g.transposed = 0; g.prec = prec; return g;
+    g.transposed = 0; g.prec = cur_prec; return g;
   }
   ConvGeom gdgrad(const ConvL& L) const {
     ConvGeom g; g.nimg = L.tokens ? N * L.tokens : N; g.ha = L.hout; g.wa = L.hout; g.ca_tot = L.cout;
     g.ho = L.hin; g.wo = L.hin; g.co_tot = L.cin_pad; g.kc = L.cout / L.groups;
     g.nc = L.cin_pad / L.groups; g.groups = L.groups; g.k = L.k; g.stride = L.stride; g.pad = L.pad;
-    g.transposed = 1; g.prec = prec; return g;
+    g.transposed = 1; g.prec = cur_prec; return g;
   }
 
   // ---- side stream: weight-gradient contractions only depend on (dy, x) of their own layer, so
@@ -901,7 +926,14 @@ struct Eng : mdd_engine {
     launch_cls_gather<AT>(T ? Q.CLS : P.CLS, T ? Q.X[vit.depth] : P.X[vit.depth], N, Tk, D, st);
     VIT_RC(mdd_op_layernorm(VDT, N, D, vit.eps, P.CLS, T ? Q.CLS : nullptr, th + off_nw, tp(th_t + off_nw),
                             th + off_nb, tp(th_t + off_nb), P.CLSN, T ? Q.CLSN : nullptr, st));
-    if (!T) {
+    if (vit.head > 0) {
+      // classifier head on the normalised class token (timm default; reference networks.py:668): small-batch fp32 linear
+      launch_act_to_f32<AT>(T ? Q.hin : P.hin, T ? Q.CLSN : P.CLSN, (int64_t)N * D, st);
+      launch_linear_fwd(P.y, T ? feat_out : nullptr, P.hin, T ? Q.hin : nullptr, th + off_hw, tp(th_t + off_hw),
+                        th + off_hb, tp(th_t + off_hb), N, D, vit.head, 0, lin_main, st);
+      if (!T && feat_out && feat_out != P.y)
+        HIP_CHECK_RET(hipMemcpyAsync(feat_out, P.y, (size_t)N * feat * 4, hipMemcpyDeviceToDevice, st));
+    } else if (!T) {
       launch_act_to_f32<AT>(P.y, P.CLSN, (int64_t)N * D, st);
       if (feat_out && feat_out != P.y)
         HIP_CHECK_RET(hipMemcpyAsync(feat_out, P.y, (size_t)N * feat * 4, hipMemcpyDeviceToDevice, st));
@@ -928,6 +960,13 @@ struct Eng : mdd_engine {
     HIP_CHECK_RET(hipMemsetAsync(gout, 0, P_img * 4, st));
     if (!T && ybar_in != O.yB)
       HIP_CHECK_RET(hipMemcpyAsync(O.yB, ybar_in, (size_t)N * feat * 4, hipMemcpyDeviceToDevice, st));
+    if (vit.head > 0) {
+      launch_linear_wgrad(gout + off_hw, gout + off_hb, O.yB, T ? ybar_t_in : nullptr, P.hin, T ? Q.hin : nullptr, N, D,
+                          vit.head, lin_main, st);
+      launch_linear_dgrad(O.hinB, T ? Q.hinB : nullptr, O.yB, T ? ybar_t_in : nullptr, th + off_hw, tp(th_t + off_hw),
+                          nullptr, N, D, vit.head, lin_main, st);
+      launch_f32_to_act<AT>(T ? Q.CLSNB : O.CLSNB, T ? Q.hinB : O.hinB, (int64_t)N * D, st);
+    } else
     launch_f32_to_act<AT>(T ? Q.CLSNB : O.CLSNB, T ? ybar_t_in : O.yB, (int64_t)N * D, st);
     VIT_RC(mdd_op_layernorm_bwd(VDT, N, D, vit.eps, P.CLS, T ? Q.CLS : nullptr, O.CLSNB, T ? Q.CLSNB : nullptr,
                                 th + off_nw, tp(th_t + off_nw), nullptr, nullptr, T ? nullptr : O.CLSB,
@@ -995,6 +1034,7 @@ struct Eng : mdd_engine {
     CHECK_ARG(base, "workspace not bound");
     DevGuard guard(device_id);
     CHECK_ARG(slot >= 0 && slot < nslots, "slot out of range");
+    select_prec(T, false);
     if (is_vit) return vit_forward(T, slot, th, th_t, image, idx, feat_out, st);
     ActSet& P = sets[slot]; ActSet& Q = tn;
     int nb = (int)blks.size();
@@ -1078,6 +1118,7 @@ struct Eng : mdd_engine {
     CHECK_ARG(base, "workspace not bound");
     DevGuard guard(device_id);
     CHECK_ARG(slot >= 0 && slot < nslots, "slot out of range");
+    select_prec(T, true);
     if (is_vit) return vit_backward(T, slot, th, th_t, ybar_in, ybar_t_in, gout, dimage, idx, coef, mul, repack, stash, st);
     ActSet& P = sets[slot]; ActSet& Q = tn;
     ActSet& O = (!T && !stash) ? tn : P;  // where primal backward signals are written
@@ -1580,6 +1621,11 @@ int mdd_flat_sgd_momentum_guarded(float* p, const float* g, float* buf, float lr
   launch_sgd_momentum(p, g, buf, lr, mom, first, n, skip_flag, (hipStream_t)stream);
   POST_LAUNCH("sgd_guarded");
   return 0;
+}
+int mdd_engine_set_pass_precision(mdd_engine* e, int fwd, int bwd, int tan_fwd, int tan_bwd) {
+  CHECK_ARG(e, "null engine");
+  const int q[4] = {fwd, bwd, tan_fwd, tan_bwd};
+  return e->set_pass_prec(q);
 }
 int mdd_engine_profile(mdd_engine* e, int enable) {
   CHECK_ARG(e, "null engine");

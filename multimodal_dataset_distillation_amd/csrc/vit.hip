@@ -239,8 +239,9 @@ __global__ void k_gelu_bwd(const AT* __restrict__ c, const AT* __restrict__ c_t,
 // ------------------------------------------------------------------ softmax over rows of fp32 scores (a wave per row)
 constexpr int SM_MAXE = 8;     // columns per lane: cols <= 512
 template <class S, class TS>
-__global__ __launch_bounds__(256) void k_softmax_fwd(const TS* __restrict__ s, const TS* __restrict__ s_t,
-                                                     TS* __restrict__ p, TS* __restrict__ p_t, int64_t rows,
+// (no __restrict__: the engine calls these in place, p == s / ds == dp; every element of a row is loaded before any
+// is stored -- the wave reduction sits in between)
+__global__ __launch_bounds__(256) void k_softmax_fwd(const TS* s, const TS* s_t, TS* p, TS* p_t, int64_t rows,
                                                      int cols, int ld, float scale) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -266,10 +267,8 @@ __global__ __launch_bounds__(256) void k_softmax_fwd(const TS* __restrict__ s, c
 }
 // ds = scale * p * (dp - sum_j p_j dp_j)
 template <class S, class TS>
-__global__ __launch_bounds__(256) void k_softmax_bwd(const TS* __restrict__ p, const TS* __restrict__ p_t,
-                                                     const TS* __restrict__ dp, const TS* __restrict__ dp_t,
-                                                     TS* __restrict__ ds, TS* __restrict__ ds_t, int64_t rows,
-                                                     int cols, int ld, float scale) {
+__global__ __launch_bounds__(256) void k_softmax_bwd(const TS* p, const TS* p_t, const TS* dp, const TS* dp_t,
+                                                     TS* ds, TS* ds_t, int64_t rows, int cols, int ld, float scale) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;

@@ -196,6 +196,11 @@ class UnrollEngine:
                                                _stream()))
         return xbd, ybd, sbd
 
+    def set_pass_precision(self, fwd=0, bwd=0, tan_fwd=0, tan_bwd=0):
+        """fp32-storage engines: operand arithmetic of the image encoder's contractions per pass
+        (0 engine mode, 1 split bf16, 2 one bf16, 3 exact fp32) -- include/mdd_hip.h."""
+        check(self.lib.mdd_engine_set_pass_precision(self.h, int(fwd), int(bwd), int(tan_fwd), int(tan_bwd)))
+
     # ------------------------------------------------------------------ whole iteration
     def unrolled_match(self, image_syn, text_syn, lr_img, lr_txt, theta0_img, theta0_txt,
                        target_img, target_txt, perms=None, drop_masks=None, syn_steps=None,

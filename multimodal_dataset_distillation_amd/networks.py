@@ -20,11 +20,14 @@ import torch.nn as nn
 from .engine import UnrollEngine
 from . import functional as Fn
 
-# reference networks.py:660-676 names -> engine topologies.  'vit' is timm's vit_tiny_patch16_224 there (:668);
-# 'vit_b16' is BASELINE configs[4]'s ViT-B/16 (build-defined: the reference's 'clip' is ViT-B/32 through the clip package)
+# reference networks.py:660-676 names -> engine topologies.  'vit' there is timm.create_model('vit_tiny_patch16_224')
+# WITHOUT num_classes=0 (:668): the model keeps timm's 1000-way head (5,717,416 parameters, 1000-d features into the
+# projection, networks.py:819) = 'vit_tiny16_cls' here, so reference-format 'vit' expert buffers flatten to P_img.
+# 'vit_tiny16' (headless, 192-d class token) and 'vit_b16' (BASELINE configs[4]'s ViT-B/16; the reference's 'clip' is
+# ViT-B/32 through the clip package) are build-defined.
 VARIANTS = {"nfnet": "nfnet_l0", "nfnet_l0": "nfnet_l0", "nfnet_l1": "nfnet_l1",
-            "nfnet_tiny": "nfnet_tiny", "vit": "vit_tiny16", "vit_tiny16": "vit_tiny16", "vit_b16": "vit_b16",
-            "vit_micro": "vit_micro"}
+            "nfnet_tiny": "nfnet_tiny", "vit": "vit_tiny16_cls", "vit_tiny16_cls": "vit_tiny16_cls",
+            "vit_tiny16": "vit_tiny16", "vit_b16": "vit_b16", "vit_micro": "vit_micro", "vit_micro_cls": "vit_micro_cls"}
 
 _ENGINES = {}
 

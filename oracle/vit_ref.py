@@ -43,12 +43,18 @@ class VitCfg:
     heads: int = 12
     mlp_ratio: float = 4.0
     eps: float = 1e-6
+    num_classes: int = 0      # > 0: timm's default classifier head Linear(D, num_classes) on the normalised class token
 
 
 VARIANTS = {
     "vit_b16": VitCfg(),                                                    # vit_base_patch16_224
     "vit_tiny16": VitCfg(dim=192, depth=12, heads=3),                       # vit_tiny_patch16_224 (networks.py:668)
     "vit_micro": VitCfg(img_size=32, patch=8, dim=64, depth=2, heads=2),    # plumbing size for goldens / GPU tests
+    # the reference's 'vit' as it stands: timm.create_model('vit_tiny_patch16_224', pretrained=True) WITHOUT
+    # num_classes=0 (networks.py:668) keeps the 1000-way head -- 5,717,416 parameters, 1000-d features into the
+    # projection (networks.py:819: image_embedding = 1000)
+    "vit_tiny16_cls": VitCfg(dim=192, depth=12, heads=3, num_classes=1000),
+    "vit_micro_cls": VitCfg(img_size=32, patch=8, dim=64, depth=2, heads=2, num_classes=24),
 }
 
 
@@ -109,19 +115,22 @@ class VisionTransformer(nn.Module):
         size = img_size or cfg.img_size
         assert size % cfg.patch == 0
         self.num_tokens = 1 + (size // cfg.patch) ** 2
-        self.num_features = cfg.dim
+        self.num_features = cfg.num_classes if cfg.num_classes > 0 else cfg.dim
         self.cls_token = nn.Parameter(torch.zeros(1, 1, cfg.dim))
         self.pos_embed = nn.Parameter(torch.randn(1, self.num_tokens, cfg.dim) * 0.02)
         self.patch_embed = PatchEmbed(cfg.patch, cfg.dim)
         self.blocks = nn.Sequential(*[Block(cfg.dim, cfg.heads, cfg.mlp_ratio, cfg.eps) for _ in range(cfg.depth)])
         self.norm = nn.LayerNorm(cfg.dim, eps=cfg.eps)
+        if cfg.num_classes > 0:
+            self.head = nn.Linear(cfg.dim, cfg.num_classes)      # registered after `norm`, as in timm
         nn.init.normal_(self.cls_token, std=1e-6)
 
     def forward(self, x):
         x = self.patch_embed(x)
         x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1) + self.pos_embed
         x = self.blocks(x)
-        return self.norm(x)[:, 0]
+        x = self.norm(x)[:, 0]
+        return self.head(x) if self.cfg.num_classes > 0 else x
 
 
 class ImageEncoder(nn.Module):

@@ -101,6 +101,19 @@ def test_param_tables_of_every_variant_match_the_oracle_flatten_order():
             assert [t[2] for t in tab] == np.cumsum([0] + fm.numels[:-1]).tolist()
         assert eng.feature_dim == enc.model.num_features
         eng.close()
+    # ViT topologies, with and without timm's classifier head (the reference's 'vit', networks.py:668, keeps it)
+    from oracle import vit_ref as vr
+    for variant, size in (("vit_micro", 32), ("vit_micro_cls", 32), ("vit_tiny16_cls", 224)):
+        eng = UnrollEngine(variant, batch=4, image_size=size, d_txt=512, syn_steps=1, dtype="bf16", bind=False)
+        fi = dr.FlatModule(vr.ImageEncoder(variant, img_size=size))
+        tab = eng.param_table("img")
+        assert [t[0] for t in tab] == fi.names and [tuple(t[1]) for t in tab] == [tuple(s) for s in fi.shapes]
+        assert eng.feature_dim == fi.module.model.num_features
+        eng.close()
+    from multimodal_dataset_distillation_amd.networks import VARIANTS
+    ev = UnrollEngine(VARIANTS["vit"], batch=4, image_size=224, d_txt=768, syn_steps=1, dtype="bf16", bind=False)
+    assert ev.P_img == 5_717_416 and ev.feature_dim == 1000     # timm's published vit_tiny_patch16_224 size, head included
+    ev.close()
     # anchors: timm's published nfnet_l0 size minus its 1000-way head
     e0 = UnrollEngine("nfnet_l0", batch=4, bind=False)
     assert e0.P_img == 32769488 and e0.P_img + 2304 * 1000 + 1000 == 35074488 and e0.P_txt == 7087104

@@ -98,6 +98,9 @@ def _case(variant, nq, batch, size, d_txt, K, seed):
     # tiles, head dim 64, the 3- / 12-head slicing of the fused qkv tensor, the 196-patch embedding at patch 16
     ("vit_tiny16", 3, 3, 224, 32, 2),      # timm vit_tiny_patch16_224 (reference networks.py:668), two unrolled steps
     ("vit_b16", 2, 2, 224, 32, 1),         # BASELINE configs[4]'s encoder
+    # with timm's classifier head on the class token = the reference's 'vit' as it stands (networks.py:668, :819)
+    ("vit_micro_cls", 5, 4, 32, 16, 2),
+    ("vit_tiny16_cls", 2, 2, 224, 32, 1),
 ])
 def test_vit_outer_iteration_matches_the_oracle(variant, nq, batch, size, d_txt, K, report):
     from multimodal_dataset_distillation_amd.engine import UnrollEngine

@@ -201,6 +201,12 @@ def test_vit_structural_anchors():
     tiny = vr.ImageEncoder("vit_tiny16")
     nt = sum(p.numel() for p in tiny.parameters())
     assert nt + 192 * 1000 + 1000 == 5_717_416                               # vit_tiny_patch16_224: 5.7 M
+    # the reference's 'vit' keeps timm's 1000-way head (networks.py:668 passes no num_classes=0): 5,717,416 parameters,
+    # registered after `norm`, 1000-d features (networks.py:819)
+    cls = vr.ImageEncoder("vit_tiny16_cls")
+    assert sum(p.numel() for p in cls.parameters()) == 5_717_416 and cls.model.num_features == 1000
+    assert [n for n, _ in cls.named_parameters()][-4:] == ["model.norm.weight", "model.norm.bias", "model.head.weight",
+                                                           "model.head.bias"]
     fm = dr.FlatModule(vr.ImageEncoder("vit_micro"))
     assert fm.names[:4] == ["model.cls_token", "model.pos_embed", "model.patch_embed.proj.weight",
                             "model.patch_embed.proj.bias"]
