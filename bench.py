@@ -92,7 +92,13 @@ def cpu_baseline(workload, seconds_budget=30.0):
             break
     dt = (time.time() - t0) / reps
     scale = (n * K) / float(sn * sK)
-    out = {"value": 1.0 / (dt * scale), "unit": "iters/sec", "cores": torch.get_num_threads(),
+    cpu_model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), None)
+    except OSError:
+        pass
+    out = {"value": 1.0 / (dt * scale), "unit": "iters/sec", "cores": torch.get_num_threads(), "cpu_model": cpu_model,
            "kind": "port", "extrapolated": scale != 1.0, "scale_factor": scale,
            "sample_iters_per_sec": 1.0 / dt, "sample_seconds_per_iter": dt, "sample_reps": reps,
            "sample": "oracle/distill_ref.py torch-CPU fp32: %d pairs x %d syn_step(s) of %s @%d timed in "

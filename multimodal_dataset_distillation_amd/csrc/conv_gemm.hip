@@ -53,7 +53,7 @@ template <> struct Mma<bf16> {
   static constexpr int KE = 64;  // K elements per 128-byte row
   static constexpr int CE = 8;   // elements per 16-byte chunk
   static DEVI u32x4 stage(const u32x4& raw, bool) { return raw; }
-  static DEVI void step(const u32x4& a, const u32x4& b, f32x16& acc, bool = false) {
+  static DEVI void step(const u32x4& a, const u32x4& b, f32x16& acc) {
     bf16x8 av = __builtin_bit_cast(bf16x8, a), bv = __builtin_bit_cast(bf16x8, b);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
   }
@@ -62,7 +62,7 @@ template <> struct Mma<float> {
   static constexpr int KE = 32;
   static constexpr int CE = 4;
   static DEVI u32x4 stage(const u32x4& raw, bool) { return raw; }
-  static DEVI void step(const u32x4& a, const u32x4& b, f32x16& acc, bool = false) {
+  static DEVI void step(const u32x4& a, const u32x4& b, f32x16& acc) {
     // lane-half h holds k = 4*(2q+h)+j, j=0..3 for BOTH operands: any k-permutation that is the
     // same for A and B leaves the sum unchanged.
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[0]), __uint_as_float(b[0]), acc, 0, 0, 0);
@@ -80,7 +80,9 @@ template <> struct Mma<float> {
 // the chunks as they stand yields hh + ll and a second one with the halves of B swapped yields hl + lh:
 // two MFMAs per four K positions (the exact-fp32 v_mfma_f32_32x32x2_f32 path needs four at twice the
 // cycles each) and no operand arithmetic inside the K loop.
-struct MmaSplit {
+// HI: the lo halves are zero (one-bf16-per-operand passes of a mixed mode, ConvGeom::prec == 2): hh is the product
+template <bool HI>
+struct MmaSplitT {
   static constexpr int KE = 32;
   static constexpr int CE = 4;
   static DEVI u32x4 stage(const u32x4& raw, bool hi_only) {
@@ -99,19 +101,17 @@ struct MmaSplit {
     o[2] = l[0] | (l[1] << 16); o[3] = l[2] | (l[3] << 16);
     return o;
   }
-  // hi: the lo halves are zero (one-bf16-per-operand passes of a mixed mode): hh is the whole product
-  static DEVI void step(const u32x4& a, const u32x4& b, f32x16& acc, bool hi = false) {
+  static DEVI void step(const u32x4& a, const u32x4& b, f32x16& acc) {
     u32x4 bs;
     bs[0] = b[2]; bs[1] = b[3]; bs[2] = b[0]; bs[3] = b[1];
     bf16x8 av = __builtin_bit_cast(bf16x8, a);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
-    if (!hi) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, bs), acc, 0, 0, 0);
+    if constexpr (!HI) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, bs), acc, 0, 0, 0);
   }
   // Two chunks of each operand at once (eight K positions per lane): regrouping their registers as
   // [h0..h7] and [l0..l7] costs no instruction and lets the ll term (below 2^-16 relative) be dropped:
   // hh + hl + lh = three MFMAs per eight K positions instead of four.
-  static DEVI void step2(const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1, f32x16& acc,
-                         bool hi = false) {
+  static DEVI void step2(const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1, f32x16& acc) {
     u32x4 ah, al, bh, bl;
     ah[0] = a0[0]; ah[1] = a0[1]; ah[2] = a1[0]; ah[3] = a1[1];
     al[0] = a0[2]; al[1] = a0[3]; al[2] = a1[2]; al[3] = a1[3];
@@ -119,13 +119,15 @@ struct MmaSplit {
     bl[0] = b0[2]; bl[1] = b0[3]; bl[2] = b1[2]; bl[3] = b1[3];
     const bf16x8 ahv = __builtin_bit_cast(bf16x8, ah), bhv = __builtin_bit_cast(bf16x8, bh);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahv, bhv, acc, 0, 0, 0);
-    if (hi) return;
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahv, __builtin_bit_cast(bf16x8, bl), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), bhv, acc, 0, 0, 0);
+    if constexpr (!HI) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahv, __builtin_bit_cast(bf16x8, bl), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), bhv, acc, 0, 0, 0);
+    }
   }
 };
 template <class AT, int PREC> struct MmaSel { typedef Mma<AT> type; };
-template <> struct MmaSel<float, 1> { typedef MmaSplit type; };
+template <> struct MmaSel<float, 1> { typedef MmaSplitT<false> type; };
+template <> struct MmaSel<float, 2> { typedef MmaSplitT<true> type; };
 
 __device__ __attribute__((aligned(16))) const unsigned g_zero_block[64] = {0};
 
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const bool hi_only = PREC == 1 && p.g.prec == 2;   // attribution experiment: fp32 stash, bf16 operands
+  constexpr bool hi_only = PREC == 2;   // fp32 stash, one bf16 per operand (mixed modes / attribution)
   auto store_tile = [&](const Stage& S) __attribute__((always_inline)) {
     if constexpr (MODE != 4) {
 #pragma unroll
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) MT::step(af[i], bf[j], acc[i][j], hi_only);
+            for (int j = 0; j < TN; ++j) MT::step(af[i], bf[j], acc[i][j]);
         }
       }
     } else
@@ -473,10 +475,10 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) MT::step(af[q & 1][i], bf[q & 1][j], acc[i][j], hi_only);
+        for (int j = 0; j < TN; ++j) MT::step(af[q & 1][i], bf[q & 1][j], acc[i][j]);
       __builtin_amdgcn_sched_barrier(0);
     }
-    } else if constexpr (PREC == 1 && MDD_SPLIT_3TERM && WGM == 2) {
+    } else if constexpr (PREC >= 1 && MDD_SPLIT_3TERM && WGM == 2) {
     // bf16x2, 2x2-wave instances: the fragments of two K-slices at once, three MFMAs per pair (step2).  The
     // 4x1-wave instances keep one slice at a time: the second fragment set does not fit their 168 registers
     // (measured: 256x64 class 144 -> 191 ms per C2 iteration with it, 128x128 class 190 -> 170 ms).
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) MT::step2(af[0][i], af[1][i], bf[0][j], bf[1][j], acc[i][j], hi_only);
+        for (int j = 0; j < TN; ++j) MT::step2(af[0][i], af[1][i], bf[0][j], bf[1][j], acc[i][j]);
     }
     } else {
 #pragma unroll
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) MT::step(af[i], bf[j], acc[i][j], hi_only);
+        for (int j = 0; j < TN; ++j) MT::step(af[i], bf[j], acc[i][j]);
     }
     }
 #pragma unroll
@@ -589,7 +591,7 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
     constexpr bool HAS_C = EM == EPI_FWD_T || EM == EPI_BWD || EM == EPI_BWD_T;   // stashed pre-activation
     constexpr bool HAS_T = EM == EPI_BWD_T;                                       // its tangent + a-bar
     constexpr bool HAS_ACT = EM != EPI_BWD_LIN;
-    const bool use_a1 = add1 != nullptr && ldop && EM != EPI_FWD && EM != EPI_FWD_T;
+    const bool use_a1 = add1 != nullptr && ldop && EM != EPI_FWD;
     const bool use_a2 = add2 != nullptr && ldop && HAS_ACT && out_act != nullptr;
     const bool do_act = HAS_ACT && out_act != nullptr;
     // four 16-byte operands per pass (tangent backward) or the parity-class row remap (MODE 2): fewer passes in flight
@@ -789,6 +791,7 @@ void launch_conv_gemm(const ConvGeom& g, const AT* A1, const AT* B1, const AT* A
 #define MDD_DISPATCH(WGM, WGN, TM, TN)                                                        \
   do {                                                                                        \
     if constexpr (sizeof(AT) == 4) {                                                          \
+      if (g.prec == 2) { MDD_DISPATCH_P(WGM, WGN, TM, TN, 2); break; }                        \
       if (g.prec != 0) { MDD_DISPATCH_P(WGM, WGN, TM, TN, 1); break; }                        \
     }                                                                                         \
     MDD_DISPATCH_P(WGM, WGN, TM, TN, 0);                                                      \

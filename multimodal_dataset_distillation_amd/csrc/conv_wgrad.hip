@@ -318,10 +318,8 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
             bf16x8 b8h = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(bh[j][0], bh[j][1], 0, 1, 2, 3, 4, 5, 6, 7));
             bf16x8 b8l = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(bl[j][0], bl[j][1], 0, 1, 2, 3, 4, 5, 6, 7));
             accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8h, a8h, accb[i][j], 0, 0, 0);
-            if (!hi_only) {    // one-bf16-per-operand passes of a mixed mode: the lo planes are zero
-              accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8l, a8h, accb[i][j], 0, 0, 0);
-              accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8h, a8l, accb[i][j], 0, 0, 0);
-            }
+            accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8l, a8h, accb[i][j], 0, 0, 0);
+            accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8h, a8l, accb[i][j], 0, 0, 0);
           }
       }
     } else if constexpr (!BF) {

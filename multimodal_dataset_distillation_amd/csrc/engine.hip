@@ -43,6 +43,10 @@ int mdd_set_error_msg(int code, const char* msg) {
 #ifndef MDD_SE_SIDE
 #define MDD_SE_SIDE 2            // forward passes: squeeze-excite gate chain beside conv3 -- 0: no (main stream),
 #endif                           // 1: on the side stream, 2: on a stream of its own with high queue priority
+#ifndef MDD_TF_SPLIT
+#define MDD_TF_SPLIT 1           // tangent-forward pass: the second source of every contraction, conv(a, w_t), depends on
+#endif                           // the primal stash only -- it runs ahead on the side stream (idle in forward passes) into the
+                                 // tangent buffer, and the main chain's conv(a_t, w) adds it in its epilogue
 #ifndef MDD_GRAPH
 #define MDD_GRAPH 0      // 1: mdd_unrolled_match replays a captured hipGraph (experiment build)
 #endif
@@ -643,6 +647,7 @@ struct Eng : mdd_engine {
     if (tside) { (void)hipStreamSynchronize(tside); (void)hipStreamDestroy(tside); }
     if (gstream) { (void)hipStreamSynchronize(gstream); (void)hipStreamDestroy(gstream); }
     for (auto e : evs) (void)hipEventDestroy(e);
+    for (auto e : tf_ev) if (e) (void)hipEventDestroy(e);
     for (auto& p : prof) { if (!p.shared_a) (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   }
   std::vector<hipEvent_t> evs;
@@ -778,10 +783,52 @@ struct Eng : mdd_engine {
       gemm(L, g, in, wf + L.off_p, nullptr, nullptr, e, st);
     } else {
       e.mode = EPI_FWD_T; e.bias_t = th_t + L.off_b; e.out_raw = C_t; e.out_act = A_t; e.c = C;
-      if (in_t) gemm(L, g, in_t, wf + L.off_p, in, wf_t + L.off_p, e, st);
+      if (in_t && tf_split_active) {   // conv(a, w_t) is already in C_t (tf_side_prepass): add it in the epilogue
+        e.add1 = C_t;
+        gemm(L, g, in_t, wf + L.off_p, nullptr, nullptr, e, st);
+      }
+      else if (in_t) gemm(L, g, in_t, wf + L.off_p, in, wf_t + L.off_p, e, st);
       else gemm(L, g, in, wf_t + L.off_p, nullptr, nullptr, e, st);
     }
   }
+  // Tangent-forward pass, second sources: raw conv(a, w_t) of every layer whose input carries a tangent, written into the
+  // layer's tangent buffer on the side stream.  They depend on the primal stash and the packed tangent weights only, so
+  // the whole sequence is enqueued at the start of the pass and runs beside the main chain; one event per block.
+  bool tf_split_active = false;
+  std::vector<hipEvent_t> tf_ev;     // [0] stem, [1 + b] block b, [nb + 1] final conv
+  void tf_raw(const ConvL& L, const AT* in, AT* dst, hipStream_t s2) {
+    ConvGeom g = gfwd(L);
+    ConvEpi e; memset(&e, 0, sizeof e);
+    e.mode = EPI_FWD; e.out_raw = dst; e.beta = 1.f;
+    gemm(L, g, in, wf_t + L.off_p, nullptr, nullptr, e, s2);
+  }
+  void tf_side_prepass(ActSet& P, ActSet& Q, hipStream_t st) {
+    const int nb = (int)blks.size();
+    if (tf_ev.size() < (size_t)nb + 2) {
+      tf_ev.resize(nb + 2, nullptr);
+      for (auto& e : tf_ev)
+        if (!e) ck(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreateWithFlags");
+    }
+    fork(st);                         // after ws_forward: the packed tangent weights exist
+    hipStream_t s2 = side;
+    for (int i = 1; i < 4; ++i) tf_raw(convs[stem[i]], P.As[i - 1], i == 3 ? Q.X[0] : Q.Cs[i], s2);
+    ck(hipEventRecord(tf_ev[0], s2), "hipEventRecord");
+    for (int b = 0; b < nb; ++b) {
+      const Blk& B = blks[b]; BlockActs& pa = P.blk[b]; BlockActs& qa = Q.blk[b];
+      if (B.ds >= 0) tf_raw(convs[B.ds], B.stride == 2 ? pa.P : P.A[b], qa.SC, s2);
+      tf_raw(convs[B.c1], P.A[b], qa.C1, s2);
+      tf_raw(convs[B.c2], pa.A1, qa.C2, s2);
+      tf_raw(convs[B.c2b], pa.A2, qa.C2b, s2);
+      tf_raw(convs[B.c3], pa.A2b, qa.C3, s2);
+      ck(hipEventRecord(tf_ev[1 + b], s2), "hipEventRecord");
+    }
+    tf_raw(convs[fin], P.X[nb], Q.CF, s2);
+    ck(hipEventRecord(tf_ev[nb + 1], s2), "hipEventRecord");
+  }
+  void tf_wait(int i, hipStream_t st) {
+    if (tf_split_active) ck(hipStreamWaitEvent(st, tf_ev[i], 0), "hipStreamWaitEvent");
+  }
+
   // Weight-gradient work is queued while a block's data-gradient chain is enqueued on the main
   // stream and released to the side stream with ONE event per block (flush_w): an event record is a
   // barrier packet on the main queue (~8-12 us bubble each), and nothing on the main stream waits for
@@ -1041,6 +1088,8 @@ struct Eng : mdd_engine {
     launch_ws_forward<AT>(d_descs, (int)descs.size(), total_rows, total_tiles, th, T ? th_t : nullptr, wf, wt,
                           wf_t, wt_t, st);
     if (!T) launch_img_gather_nhwc<AT>(P.X0, image, idx, N, 3, S, S, 8, st);
+    tf_split_active = T && use_side && MDD_TF_SPLIT;
+    if (tf_split_active) { tf_side_prepass(P, Q, st); tf_wait(0, st); }
     const AT* in = P.X0; const AT* in_t = nullptr;
     for (int i = 0; i < 4; ++i) {
       bool last = i == 3;
@@ -1055,11 +1104,13 @@ struct Eng : mdd_engine {
       const AT *x = P.X[b], *x_t = Q.X[b], *a = P.A[b], *a_t = Q.A[b];
       const AT *sc = x, *sc_t = x_t;
       bool sc_forked = false;
+      tf_wait(1 + b, st);
       if (B.ds >= 0) {
         // the shortcut (avg-pool + 1x1 conv) only meets the residual branch at the SE apply: it runs on
-        // the side stream, which is idle during forward passes
+        // the side stream, which is idle during forward passes (not in a split tangent pass: the side stream is busy
+        // with the second sources then)
         hipStream_t ss = st;
-        if (use_side && MDD_FWD_SHORTCUT_SIDE) { fork(st); ss = side; sc_forked = true; }
+        if (use_side && MDD_FWD_SHORTCUT_SIDE && !tf_split_active) { fork(st); ss = side; sc_forked = true; }
         const AT *din = a, *din_t = a_t;
         if (B.stride == 2) {
           launch_avgpool2<AT>(T ? qa.P : pa.P, T ? a_t : a, N, B.hin, B.hin, B.cin, 2, ss);
@@ -1102,7 +1153,9 @@ struct Eng : mdd_engine {
                           lastb ? nullptr : P.A[b + 1], (T && !lastb) ? Q.A[b + 1] : nullptr, ga,
                           lastb ? 1.f : blks[b + 1].beta, N, hw, c, st);
     }
+    tf_wait(nb + 1, st);
     conv_fwd(T, convs[fin], P.X[nb], Q.X[nb], P.CF, Q.CF, nullptr, nullptr, 1.f, th, th_t, st);
+    if (tf_split_active) { join(st); tf_split_active = false; }
     int hwf = xh[nb] * xh[nb];
     launch_final_pool<AT>(P.y, T ? feat_out : nullptr, P.CF, T ? Q.CF : nullptr, N, hwf, feat, st);
     if (!T && feat_out && feat_out != P.y)

@@ -71,7 +71,7 @@ struct ConvEpi {
 };
 enum {
   EPI_FWD = 0,        // c = acc + bias ; out_raw = c ; out_act = beta*silu(c)
-  EPI_FWD_T = 1,      // c = Dual(c, acc + bias_t); out_raw = c.t ; out_act = (beta*silu(c)).t
+  EPI_FWD_T = 1,      // c = Dual(c, acc + bias_t + add1); out_raw = c.t ; out_act = (beta*silu(c)).t
   EPI_BWD = 2,        // a = acc + add1 ; out_raw = a ; out_act = beta*dsilu(c)*a + add2
   EPI_BWD_T = 3,      // a = Dual(abar, acc + add1); out_act = (beta*dsilu(Dual(c,c_t))*a).t + add2
   EPI_BWD_LIN = 4,    // a = acc + add1 ; out_raw = a     (no activation in between)
