@@ -38,7 +38,7 @@ PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 KIND_NAMES = ["conv_gemm<128x32>", "conv_gemm<256x64>", "conv_gemm<128x128>", "conv_wgrad", "k_wgrad_reduce"]
-TRAFFIC_FILES = ["traffic_r02.json", "traffic_r01.json"]      # newest first
+TRAFFIC_FILES = ["traffic_r03.json", "traffic_r02.json", "traffic_r01.json"]      # newest first
 # Budget for the post-timing self-check: relative error of the benched mode's outer gradients against ONE
 # f32-mode (exact-fp32 MFMA) iteration on the same inputs.  ~2x the errors measured on MI355X.
 SELFCHECK_BUDGET = {"bf16": dict(grand=5e-3, g_img=1e-1, g_txt=9e-2, g_lr=2e-2),
@@ -243,7 +243,9 @@ def main():
     out = dict(image_syn=views["image_syn"], text_syn=views["text_syn"], lr=views["lr"],
                losses=torch.zeros(3 + K, device=dev))
     mom = torch.zeros_like(flat_grad)
-    libcoll = par.LibraryCollective(dev) if (world > 1 and args.collective == "library") else None
+    # --collective library also at N=1: the step then still goes through mdd_comm_create / mdd_allreduce_syn_grads
+    # (a one-rank communicator), so the same command line exercises the library-owned RCCL path at any N
+    libcoll = par.LibraryCollective(dev) if args.collective == "library" else None
     SGD_LR_SCALE = 1e-6
     ar_events = []          # (start, end) HIP events around each all-reduce (current stream)
     params = [(image_syn, 0, n_img, 1000.0), (text_syn, n_img, n_txt, 1000.0),
@@ -266,7 +268,7 @@ def main():
             a0i, a0t, ati, att = xs["buf"][slot].split(xs["split"])
         eng.unrolled_match(image_syn, text_syn, lr[0:1], lr[1:2], a0i, a0t, ati, att, perms=perms,
                            out=out)
-        if world > 1:
+        if world > 1 or libcoll is not None:
             ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ea.record()
             if libcoll is not None:
@@ -311,6 +313,8 @@ def main():
     gnorm = dict(grad_image_syn=float(out["image_syn"].norm()), grad_text_syn=float(out["text_syn"].norm()),
                  grad_lr=[float(v) for v in out["lr"].tolist()])
     rank_losses, ar_ms = [losses[0]], None
+    if world == 1 and ar_events:
+        ar_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(1, len(ar_events))
     if world > 1:
         gl = [torch.zeros(1, device=dev) for _ in range(world)]
         dist.all_gather(gl, torch.tensor([losses[0]], device=dev))
@@ -341,7 +345,7 @@ def main():
                        "keep_steps": eng.keep_steps, "workspace_gib": eng.workspace_bytes / 2**30,
                        "parallelism": "expert-replica x%d (1 all-reduce/step)" % world,
                        "collective_backend": args.dist_backend if world > 1 else None,
-                       "collective_issued_by": (args.collective if world > 1 else None)},
+                       "collective_issued_by": (args.collective if (world > 1 or libcoll is not None) else None)},
             "grand_loss": losses[0], "grand_loss_per_rank": rank_losses,
             "grad_norms": gnorm,
             "sgd_lr_scale": SGD_LR_SCALE,
@@ -551,6 +555,8 @@ def main():
         result["other_workloads"] = others
     if rank == 0:
         print(json.dumps(result))
+    if libcoll is not None:
+        libcoll.close()       # ncclCommDestroy before torch's process group goes away
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -44,9 +44,10 @@ int mdd_set_error_msg(int code, const char* msg) {
 #define MDD_SE_SIDE 2            // forward passes: squeeze-excite gate chain beside conv3 -- 0: no (main stream),
 #endif                           // 1: on the side stream, 2: on a stream of its own with high queue priority
 #ifndef MDD_TF_SPLIT
-#define MDD_TF_SPLIT 1           // tangent-forward pass: the second source of every contraction, conv(a, w_t), depends on
-#endif                           // the primal stash only -- it runs ahead on the side stream (idle in forward passes) into the
-                                 // tangent buffer, and the main chain's conv(a_t, w) adds it in its epilogue
+#define MDD_TF_SPLIT 0           // experiment (profiles/r03_experiments.md: +2.7 % time, rejected): tangent-forward pass,
+#endif                           // the second source of every contraction, conv(a, w_t), depends on the primal stash only --
+                                 // it runs ahead on the side stream (idle in forward passes) into the tangent buffer and
+                                 // the main chain's conv(a_t, w) adds it in its epilogue
 #ifndef MDD_GRAPH
 #define MDD_GRAPH 0      // 1: mdd_unrolled_match replays a captured hipGraph (experiment build)
 #endif

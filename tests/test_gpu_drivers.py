@@ -63,13 +63,24 @@ def test_real_init_decode_and_eval_hook(report, tmp_path, capsys):
     nw.release_engines()
 
 
-@pytest.mark.parametrize("mode", ["A", "B"])
+@pytest.mark.parametrize("mode", ["A", "B", "A-real"])
 def test_two_ranks_on_one_gpu_with_the_engine_in_the_loop(mode, report, tmp_path):
     """torch.distributed.run, 2 ranks, gloo (RCCL refuses two ranks on one device).
     mode A: every rank runs the fused engine on its own synthetic expert, the fused [grads | NaN flag] buffer
     is all-reduced; mode B (`--distributed`, the reference flag's meaning): every rank runs the unrolled loop
     on its half of each minibatch, features all-gathered and gradients all-reduced inside the loop.
-    Both ranks must end with the identical synthetic set (saved by rank 0 and rank 1 separately)."""
+    Both ranks must end with the identical synthetic set (saved by rank 0 and rank 1 separately).
+    A-real: mode A with the fork's real-pair initialisation (reference distill.py:97-105, 228: a numpy permutation
+    of the training pairs) and NO common torch seed in the rank script -- the drawn set must still be the same on
+    every rank (it was drawn with a per-rank numpy seed and never broadcast)."""
+    extra = ["--distributed"] if mode == "B" else []
+    if mode == "A-real":
+        rs = np.random.RandomState(3)
+        np.savez(os.path.join(tmp_path, "flickr_bert_train_text_embed.npz"),
+                 bert_test_embed=rs.randn(40, 768).astype(np.float32))
+        torch.save(torch.from_numpy(rs.randn(40, 3, 64, 64).astype(np.float32)), os.path.join(tmp_path, "train_images.pt"))
+        extra = ["--dataset", "flickr", "--embed_dir", str(tmp_path), "--pix_init", "real", "--txt_init", "real",
+                 "--train_images", os.path.join(tmp_path, "train_images.pt")]
     script = os.path.join(tmp_path, "run_rank.py")
     with open(script, "w") as f:
         f.write(
@@ -81,13 +92,14 @@ def test_two_ranks_on_one_gpu_with_the_engine_in_the_loop(mode, report, tmp_path
             "        '--lr_img','0.5','--lr_txt','0.5','--lr_lr','1e-5','--synthetic_experts','3','4',\n"
             "        '--compute_dtype','f32','--dist_backend','gloo','--seed','5'] + %r\n"
             "args, _ = distill.build_parser().parse_known_args(argv)\n"
-            "torch.manual_seed(0)\n"
+            "torch.manual_seed(0 if %r != 'A-real' else 1000 + int(os.environ['RANK']))\n"
             "img, txt, lr = distill.main(args)\n"
             "torch.save({'img': img.cpu(), 'txt': txt.cpu(), 'lr': lr.cpu()}, os.path.join(%r, 'rank%%s.pt' %% os.environ['RANK']))\n"
-            % (ROOT, ["--distributed"] if mode == "B" else [], str(tmp_path)))
+            % (ROOT, extra, mode, str(tmp_path)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29617" if mode == "A" else "29618", script],
+                        "--master-addr", "127.0.0.1", "--master-port",
+                        {"A": "29617", "B": "29618", "A-real": "29619"}[mode], script],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     a = torch.load(os.path.join(tmp_path, "rank0.pt"), weights_only=True)
