@@ -182,7 +182,8 @@ int mdd_unrolled_match(mdd_engine* e, const mdd_iter_args* a, void* stream);
 int mdd_engine_profile(mdd_engine* e, int enable);
 /* fp32-storage engines (MDD_DTYPE_F32 / _BF16X2 / _F32_BF16OPS): operand arithmetic of the image encoder's
  * contractions per pass -- F (reference distill.py:524), B (:562-567), T-F and T-B (what :606 differentiates):
- * 0 = the engine's own mode, 1 = split-bf16 (hi + lo), 2 = one bf16 per operand, 3 = exact fp32 MFMA.  Used for the
+ * 0 = the engine's own mode, 1 = split-bf16 (hi + lo), 2 = one bf16 per operand, 3 = exact fp32 MFMA, 4 = one fp16 per
+ * operand (experiment: what an fp16-storage engine's matrix cores would see).  Used for the
  * per-pass error attribution and for mixed parity-grade modes. */
 int mdd_engine_set_pass_precision(mdd_engine* e, int fwd, int bwd, int tan_fwd, int tan_bwd);
 int mdd_engine_profile_read(mdd_engine* e, int kind, double* out4);

@@ -125,7 +125,35 @@ struct MmaSplitT {
     }
   }
 };
+// fp32 storage, ONE fp16 per operand (ConvGeom::prec == 3): the precision experiment of DESIGN.md section 5 -- what an
+// fp16-storage engine's matrix cores would see (11 significand bits instead of bf16's 8, narrower exponent range)
+struct MmaF16Ops {
+  static constexpr int KE = 32;
+  static constexpr int CE = 4;
+  static DEVI u32x4 stage(const u32x4& raw, bool) {
+    unsigned h[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      _Float16 hh = (_Float16)__uint_as_float(raw[i]);
+      h[i] = (unsigned)__builtin_bit_cast(unsigned short, hh);
+    }
+    u32x4 o;
+    o[0] = h[0] | (h[1] << 16); o[1] = h[2] | (h[3] << 16); o[2] = 0u; o[3] = 0u;
+    return o;
+  }
+  static DEVI void step(const u32x4& a, const u32x4& b, f32x16& acc) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+  }
+  static DEVI void step2(const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1, f32x16& acc) {
+    u32x4 ah, bh;
+    ah[0] = a0[0]; ah[1] = a0[1]; ah[2] = a1[0]; ah[3] = a1[1];
+    bh[0] = b0[0]; bh[1] = b0[1]; bh[2] = b1[0]; bh[3] = b1[1];
+    step(ah, bh, acc);
+  }
+};
 template <class AT, int PREC> struct MmaSel { typedef Mma<AT> type; };
+template <> struct MmaSel<float, 3> { typedef MmaF16Ops type; };
 template <> struct MmaSel<float, 1> { typedef MmaSplitT<false> type; };
 template <> struct MmaSel<float, 2> { typedef MmaSplitT<true> type; };
 
@@ -146,7 +174,12 @@ struct KArgs {
   int M, mtiles, ntiles, dbg;
 };
 
-template <class AT, int WGM, int WGN, int TM, int TN, int MODE, bool KFULL, int PREC, bool IBK = false>
+// activation of the fused epilogues: 0 = SiLU (NFNet), 1 = exact GELU (the ViT MLP: fc1's forward and fc2's data gradient)
+template <int ACT> DEVI float actf(float x) { if constexpr (ACT == 1) return gelu_(x); else return silu_(x); }
+template <int ACT> DEVI float dactf(float x) { if constexpr (ACT == 1) return dgelu_(x); else return dsilu_(x); }
+template <int ACT> DEVI Dual dactf(Dual x) { if constexpr (ACT == 1) return dgelu_(x); else return dsilu_(x); }
+
+template <class AT, int WGM, int WGN, int TM, int TN, int MODE, bool KFULL, int PREC, bool IBK = false, int ACT = 0>
 __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   constexpr int RA = BM / 32, RB = BN / 32;
@@ -675,15 +708,15 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
               for (int e = 0; e < CE; ++e) o[e] = v[e];
             } else if constexpr (EM == EPI_FWD) {
 #pragma unroll
-              for (int e = 0; e < CE; ++e) o[e] = beta * silu_(v[e]);
+              for (int e = 0; e < CE; ++e) o[e] = beta * actf<ACT>(v[e]);
             } else if constexpr (EM == EPI_BWD_T) {
               Chunk<AT>::unpack(q_c[u], t0); Chunk<AT>::unpack(q_ct[u], t1); Chunk<AT>::unpack(q_ab[u], t2);
 #pragma unroll
-              for (int e = 0; e < CE; ++e) o[e] = beta * (dsilu_(Dual(t0[e], t1[e])) * Dual(t2[e], v[e])).t;
+              for (int e = 0; e < CE; ++e) o[e] = beta * (dactf<ACT>(Dual(t0[e], t1[e])) * Dual(t2[e], v[e])).t;
             } else {   // EPI_FWD_T, EPI_BWD
               Chunk<AT>::unpack(q_c[u], t0);
 #pragma unroll
-              for (int e = 0; e < CE; ++e) o[e] = beta * dsilu_(t0[e]) * v[e];
+              for (int e = 0; e < CE; ++e) o[e] = beta * dactf<ACT>(t0[e]) * v[e];
             }
             if (use_a2) {
               Chunk<AT>::unpack(q_a2[u], t0);
@@ -720,7 +753,7 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
 }
 
 
-template <class AT, int WGM, int WGN, int TM, int TN, int MODE, bool KFULL, int PREC, bool IBK = false>
+template <class AT, int WGM, int WGN, int TM, int TN, int MODE, bool KFULL, int PREC, bool IBK = false, int ACT = 0>
 void launch_cfg(const KArgs& a, hipStream_t st) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   KArgs k = a;
@@ -737,13 +770,13 @@ void launch_cfg(const KArgs& a, hipStream_t st) {
   (void)hipGetDevice(&dev);
   const uint64_t bit = 1ull << (dev & 63);
   if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_conv_gemm<AT, WGM, WGN, TM, TN, MODE, KFULL, PREC, IBK>,
+    hipError_t e = hipFuncSetAttribute((const void*)k_conv_gemm<AT, WGM, WGN, TM, TN, MODE, KFULL, PREC, IBK, ACT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        MODE == 4 ? (int)MODE4_MAX_LDS : (int)shm);
     if (e == hipSuccess) attr_devs.fetch_or(bit, std::memory_order_release);
   }
   int64_t blocks = (int64_t)k.mtiles * k.ntiles * a.g.groups;
-  k_conv_gemm<AT, WGM, WGN, TM, TN, MODE, KFULL, PREC, IBK><<<(unsigned)blocks, 256, shm, st>>>(k);
+  k_conv_gemm<AT, WGM, WGN, TM, TN, MODE, KFULL, PREC, IBK, ACT><<<(unsigned)blocks, 256, shm, st>>>(k);
 }
 
 }  // namespace
@@ -791,11 +824,24 @@ void launch_conv_gemm(const ConvGeom& g, const AT* A1, const AT* B1, const AT* A
 #define MDD_DISPATCH(WGM, WGN, TM, TN)                                                        \
   do {                                                                                        \
     if constexpr (sizeof(AT) == 4) {                                                          \
+      if (g.prec == 3) { MDD_DISPATCH_P(WGM, WGN, TM, TN, 3); break; }                        \
       if (g.prec == 2) { MDD_DISPATCH_P(WGM, WGN, TM, TN, 2); break; }                        \
       if (g.prec != 0) { MDD_DISPATCH_P(WGM, WGN, TM, TN, 1); break; }                        \
     }                                                                                         \
     MDD_DISPATCH_P(WGM, WGN, TM, TN, 0);                                                      \
   } while (0)
+  if (ep.act == 1) {
+    // exact-GELU epilogues (ViT MLP): own instances of the 128 x 128 pointwise kernel, so that the erf path's
+    // registers do not weigh on the SiLU instances (a run-time switch cost the NFNet iteration +10 %, round 2);
+    // conv_gemm_supports_gelu() tells the engine when it may ask for them
+    if constexpr (sizeof(AT) == 4) {
+      if (g.prec == 2 || g.prec == 3) { if (kfull) launch_cfg<AT, 2, 2, 2, 2, 0, true, 2, false, 1>(a, st); else launch_cfg<AT, 2, 2, 2, 2, 0, false, 2, false, 1>(a, st); return; }
+      if (g.prec == 1) { if (kfull) launch_cfg<AT, 2, 2, 2, 2, 0, true, 1, false, 1>(a, st); else launch_cfg<AT, 2, 2, 2, 2, 0, false, 1, false, 1>(a, st); return; }
+    }
+    if (kfull) launch_cfg<AT, 2, 2, 2, 2, 0, true, 0, false, 1>(a, st);
+    else launch_cfg<AT, 2, 2, 2, 2, 0, false, 0, false, 1>(a, st);
+    return;
+  }
   if (g.nc <= 32) MDD_DISPATCH(4, 1, 1, 1);        // 128 x 32  (stem)
   else if (g.nc <= 64) MDD_DISPATCH(4, 1, 2, 2);   // 256 x 64  (group width 64)
 #if MDD_BIG_TILE == 0
@@ -807,6 +853,10 @@ void launch_conv_gemm(const ConvGeom& g, const AT* A1, const AT* B1, const AT* A
 #endif
 #undef MDD_DISPATCH
 #undef MDD_DISPATCH_P
+}
+// GELU epilogues: pointwise contractions on the 128 x 128 tile (output width per group > 64)
+bool conv_gemm_supports_gelu(const ConvGeom& g) {
+  return g.k == 1 && g.stride == 1 && g.pad == 0 && g.groups == 1 && g.nc > 64;
 }
 template void launch_conv_gemm<float>(const ConvGeom&, const float*, const float*, const float*,
                                       const float*, const ConvEpi&, hipStream_t);

@@ -62,7 +62,9 @@ template <int ROWB> DEVI int wswz(int row) { return ROWB == 128 ? ((row >> 1) & 
 // SPLIT (fp32 storage only): split-bf16 math -- each fp32 element is split into hi = bf16(x) and
 // lo = bf16(x - hi) between the global load and the LDS store, into two bf16 planes with the bf16 path's
 // layout; the contraction is hh + hl + lh on v_mfma_f32_16x16x32_bf16 (the ll term is below 2^-16 relative).
-template <class AT, int BCO, int BKP, int BKM, bool PW, bool PF2, bool SPLIT>
+// F16OPS (with SPLIT; ConvGeom::prec == 3): the fp32 operands are rounded to ONE fp16 each (11 significand bits)
+// and multiplied by v_mfma_f32_16x16x32_f16 -- the precision experiment of DESIGN.md section 5
+template <class AT, int BCO, int BKP, int BKM, bool PW, bool PF2, bool SPLIT, bool F16OPS = false>
 __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArgs p) {
   constexpr int CE = 16 / (int)sizeof(AT);
   constexpr bool BF = sizeof(AT) == 2;
@@ -215,10 +217,16 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float f = __uint_as_float(raw[e]);
-        bf16 hb = (bf16)f;
-        h[e] = (unsigned)__builtin_bit_cast(unsigned short, hb);
-        bf16 lb = (bf16)(f - __uint_as_float(h[e] << 16));
-        l[e] = hi_only ? 0u : (unsigned)__builtin_bit_cast(unsigned short, lb);
+        if constexpr (F16OPS) {
+          _Float16 hh = (_Float16)f;
+          h[e] = (unsigned)__builtin_bit_cast(unsigned short, hh);
+          l[e] = 0u;
+        } else {
+          bf16 hb = (bf16)f;
+          h[e] = (unsigned)__builtin_bit_cast(unsigned short, hb);
+          bf16 lb = (bf16)(f - __uint_as_float(h[e] << 16));
+          l[e] = hi_only ? 0u : (unsigned)__builtin_bit_cast(unsigned short, lb);
+        }
       }
       char* a = plane_hi + r * row_bytes + unit * 8;
       *(uint2*)a = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
@@ -317,9 +325,15 @@ __global__ __launch_bounds__(256, MDD_WG_MIN_WAVES) void k_conv_wgrad(const WArg
             bf16x8 a8l = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(al[i][0], al[i][1], 0, 1, 2, 3, 4, 5, 6, 7));
             bf16x8 b8h = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(bh[j][0], bh[j][1], 0, 1, 2, 3, 4, 5, 6, 7));
             bf16x8 b8l = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(bl[j][0], bl[j][1], 0, 1, 2, 3, 4, 5, 6, 7));
-            accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8h, a8h, accb[i][j], 0, 0, 0);
-            accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8l, a8h, accb[i][j], 0, 0, 0);
-            accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8h, a8l, accb[i][j], 0, 0, 0);
+            if constexpr (F16OPS) {
+              typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+              accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, b8h), __builtin_bit_cast(f16x8, a8h),
+                                                                  accb[i][j], 0, 0, 0);
+            } else {
+              accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8h, a8h, accb[i][j], 0, 0, 0);
+              accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8l, a8h, accb[i][j], 0, 0, 0);
+              accb[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8h, a8l, accb[i][j], 0, 0, 0);
+            }
           }
       }
     } else if constexpr (!BF) {
@@ -523,6 +537,12 @@ void launch_cfg(WArgs a, float* slab, int64_t slab_floats, hipEvent_t ev_mid, hi
   };
   constexpr bool PF2 = MDD_WG_PF2 && sizeof(AT) == 2 && BCO == 128;   // 2 waves/SIMD either way there
   if constexpr (sizeof(AT) == 4) {
+    if (g.prec == 3) {
+      if (pw) k_conv_wgrad<AT, BCO, BKP, BKM, true, false, true, true><<<grid, 256, 0, st>>>(a);
+      else k_conv_wgrad<AT, BCO, BKP, BKM, false, false, true, true><<<grid, 256, 0, st>>>(a);
+      finish();
+      return;
+    }
     if (g.prec != 0) {
       if (pw) k_conv_wgrad<AT, BCO, BKP, BKM, true, false, true><<<grid, 256, 0, st>>>(a);
       else k_conv_wgrad<AT, BCO, BKP, BKM, false, false, true><<<grid, 256, 0, st>>>(a);

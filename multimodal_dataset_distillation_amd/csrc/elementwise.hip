@@ -284,10 +284,8 @@ __global__ void k_hw_reduce(float* __restrict__ out, float* __restrict__ out_t,
 #pragma unroll
       for (int e = 0; e < CE; ++e) gs[e] = ldS<S>(gate, gate_t, (size_t)ni * c + (size_t)col * CE + e) * mul;
     }
-    for (int p = lane; p < hw; p += 32) {
-      int64_t ci = ((int64_t)ni * hw + p) * cch + col;
-      S x[CE];
-      ld_chunkS<S, AT>(a, a_t, ci, x);
+    // two rows per trip: both rows' chunks (2 or 4 sixteen-byte loads per operand pair) are in flight together
+    auto body = [&](const S* x, const S* y, int64_t ci) __attribute__((always_inline)) {
       if constexpr (MODE == 3) {
         S o[CE];
 #pragma unroll
@@ -301,11 +299,26 @@ __global__ void k_hw_reduce(float* __restrict__ out, float* __restrict__ out_t,
 #pragma unroll
         for (int e = 0; e < CE; ++e) acc[e] = acc[e] + silu_(x[e]);
       } else {
-        S y[CE];
-        ld_chunkS<S, AT>(b, b_t, ci, y);
 #pragma unroll
         for (int e = 0; e < CE; ++e) acc[e] = acc[e] + x[e] * y[e];
       }
+    };
+    int p = lane;
+    for (; p + 32 < hw; p += 64) {
+      const int64_t c0 = ((int64_t)ni * hw + p) * cch + col, c1 = c0 + (int64_t)32 * cch;
+      S x0[CE], x1[CE], y0[MODE >= 2 ? CE : 1], y1[MODE >= 2 ? CE : 1];
+      ld_chunkS<S, AT>(a, a_t, c0, x0);
+      ld_chunkS<S, AT>(a, a_t, c1, x1);
+      if constexpr (MODE >= 2) { ld_chunkS<S, AT>(b, b_t, c0, y0); ld_chunkS<S, AT>(b, b_t, c1, y1); }
+      body(x0, y0, c0);
+      body(x1, y1, c1);
+    }
+    if (p < hw) {
+      const int64_t c0 = ((int64_t)ni * hw + p) * cch + col;
+      S x0[CE], y0[MODE >= 2 ? CE : 1];
+      ld_chunkS<S, AT>(a, a_t, c0, x0);
+      if constexpr (MODE >= 2) ld_chunkS<S, AT>(b, b_t, c0, y0);
+      body(x0, y0, c0);
     }
   }
   // reduce over the 32 hw lanes through LDS: sh[lane][colslot][e]

@@ -43,6 +43,9 @@ int mdd_set_error_msg(int code, const char* msg) {
 #ifndef MDD_SE_SIDE
 #define MDD_SE_SIDE 2            // forward passes: squeeze-excite gate chain beside conv3 -- 0: no (main stream),
 #endif                           // 1: on the side stream, 2: on a stream of its own with high queue priority
+#ifndef MDD_VIT_FUSE_GELU
+#define MDD_VIT_FUSE_GELU 1      // ViT MLP: exact GELU (and its chain rule) in the epilogues of fc1 / fc2's data gradient
+#endif
 #ifndef MDD_TF_SPLIT
 #define MDD_TF_SPLIT 0           // experiment (profiles/r03_experiments.md: +2.7 % time, rejected): tangent-forward pass,
 #endif                           // the second source of every contraction, conv(a, w_t), depends on the primal stash only --
@@ -188,11 +191,11 @@ struct Eng : mdd_engine {
   int cur_prec = 0;
   void select_prec(bool T, bool bwd) {
     const int q = pass_prec[(T ? 2 : 0) + (bwd ? 1 : 0)];
-    cur_prec = (sizeof(AT) == 4 && q != 0) ? (q == 3 ? 0 : q) : prec;
+    cur_prec = (sizeof(AT) == 4 && q != 0) ? (q == 3 ? 0 : (q == 4 ? 3 : q)) : prec;
   }
   int set_pass_prec(const int* q) override {
     for (int i = 0; i < 4; ++i) {
-      CHECK_ARG(q[i] >= 0 && q[i] <= 3, "pass precision must be 0 (engine mode), 1 (split bf16), 2 (one bf16), 3 (exact fp32)");
+      CHECK_ARG(q[i] >= 0 && q[i] <= 4, "pass precision must be 0 (engine mode), 1 (split bf16), 2 (one bf16), 3 (exact fp32), 4 (one fp16)");
       pass_prec[i] = q[i];
     }
     CHECK_ARG(sizeof(AT) == 4 || (q[0] | q[1] | q[2] | q[3]) == 0, "per-pass precision needs an fp32-storage engine");
@@ -775,10 +778,10 @@ struct Eng : mdd_engine {
 
   // c = conv(in) + bias ; C <- c ; A <- beta*silu(c).   T: tangent of the same (primal from stash)
   void conv_fwd(bool T, const ConvL& L, const AT* in, const AT* in_t, AT* C, AT* C_t, AT* A,
-                AT* A_t, float beta, const float* th, const float* th_t, hipStream_t st) {
+                AT* A_t, float beta, const float* th, const float* th_t, hipStream_t st, int act = 0) {
     ConvGeom g = gfwd(L);
     ConvEpi e; memset(&e, 0, sizeof e);
-    e.beta = beta;
+    e.beta = beta; e.act = act;
     if (!T) {
       e.mode = EPI_FWD; e.bias = th + L.off_b; e.out_raw = C; e.out_act = A;
       gemm(L, g, in, wf + L.off_p, nullptr, nullptr, e, st);
@@ -964,8 +967,14 @@ struct Eng : mdd_engine {
       launch_add2<AT>(pa.X2, T ? qa.X2 : nullptr, x, x_t, P.TMP, T ? Q.TMP : nullptr, (int64_t)M * D, st);
       VIT_RC(mdd_op_layernorm(VDT, M, D, vit.eps, pa.X2, T ? qa.X2 : nullptr, th + B.ln2_w, tp(th_t + B.ln2_w),
                               th + B.ln2_b, tp(th_t + B.ln2_b), pa.N2, T ? qa.N2 : nullptr, st));
-      conv_fwd(T, convs[B.fc1], pa.N2, qa.N2, pa.C, qa.C, nullptr, nullptr, 1.f, th, th_t, st);
-      VIT_RC(mdd_op_gelu(VDT, (int64_t)M * 4 * D, pa.C, T ? qa.C : nullptr, pa.A, T ? qa.A : nullptr, st));
+      // fc1 with the exact GELU in its epilogue (C and A = gelu(C) written by the contraction; tangent: C_t and
+      // A_t = gelu'(C) C_t) wherever the GELU instance of the kernel exists for this width
+      if (MDD_VIT_FUSE_GELU && conv_gemm_supports_gelu(gfwd(convs[B.fc1]))) {
+        conv_fwd(T, convs[B.fc1], pa.N2, qa.N2, pa.C, qa.C, pa.A, qa.A, 1.f, th, th_t, st, 1);
+      } else {
+        conv_fwd(T, convs[B.fc1], pa.N2, qa.N2, pa.C, qa.C, nullptr, nullptr, 1.f, th, th_t, st);
+        VIT_RC(mdd_op_gelu(VDT, (int64_t)M * 4 * D, pa.C, T ? qa.C : nullptr, pa.A, T ? qa.A : nullptr, st));
+      }
       conv_fwd(T, convs[B.fc2], pa.A, qa.A, P.TMP, Q.TMP, nullptr, nullptr, 1.f, th, th_t, st);
       launch_add2<AT>(P.X[l + 1], T ? Q.X[l + 1] : nullptr, pa.X2, T ? qa.X2 : nullptr, P.TMP, T ? Q.TMP : nullptr,
                       (int64_t)M * D, st);
@@ -1025,9 +1034,17 @@ struct Eng : mdd_engine {
       const AT *xb = O.XB[l + 1], *xb_t = Q.XB[l + 1];
       // MLP branch
       lin_bwd_w(T, convs[B.fc2], xb, xb_t, pa.A, qa.A, gout, st);
-      conv_bwd_d(T, convs[B.fc2], xb, xb_t, epi_lin(T ? qa.AB : oa.AB, nullptr), st);
-      VIT_RC(mdd_op_gelu_bwd(VDT, (int64_t)M * 4 * D, pa.C, T ? qa.C : nullptr, oa.AB, T ? qa.AB : nullptr,
-                             T ? nullptr : oa.CB, T ? qa.CB : nullptr, st));
+      if (MDD_VIT_FUSE_GELU && conv_gemm_supports_gelu(gdgrad(convs[B.fc2]))) {
+        // fc2's data gradient with the GELU chain rule in its epilogue: raw AB (stashed: the tangent pass needs it)
+        // and CB = gelu'(C) AB; tangent: CB_t = (gelu'(Dual(C, C_t)) Dual(AB, AB_t)).t from the stashed C, C_t, AB
+        ConvEpi eg = epi_act(T, oa.AB, oa.CB, qa.CB, pa.C, qa.C, 1.f, nullptr, nullptr);
+        eg.act = 1;
+        conv_bwd_d(T, convs[B.fc2], xb, xb_t, eg, st);
+      } else {
+        conv_bwd_d(T, convs[B.fc2], xb, xb_t, epi_lin(T ? qa.AB : oa.AB, nullptr), st);
+        VIT_RC(mdd_op_gelu_bwd(VDT, (int64_t)M * 4 * D, pa.C, T ? qa.C : nullptr, oa.AB, T ? qa.AB : nullptr,
+                               T ? nullptr : oa.CB, T ? qa.CB : nullptr, st));
+      }
       lin_bwd_w(T, convs[B.fc1], oa.CB, qa.CB, pa.N2, qa.N2, gout, st);
       conv_bwd_d(T, convs[B.fc1], oa.CB, qa.CB, epi_lin(T ? qa.N2B : oa.N2B, nullptr), st);
       VIT_RC(mdd_op_layernorm_bwd(VDT, M, D, vit.eps, pa.X2, T ? qa.X2 : nullptr, oa.N2B, T ? qa.N2B : nullptr,

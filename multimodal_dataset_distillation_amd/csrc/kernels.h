@@ -68,6 +68,7 @@ struct ConvEpi {
   const float* ib_t;
   float ib_mul;
   int ib_hw;
+  int act;                // activation of the fused chain rule: 0 SiLU, 1 exact GELU (conv_gemm_supports_gelu)
 };
 enum {
   EPI_FWD = 0,        // c = acc + bias ; out_raw = c ; out_act = beta*silu(c)
@@ -90,6 +91,7 @@ struct ConvGeom {
 template <class AT>
 void launch_conv_gemm(const ConvGeom& g, const AT* A1, const AT* B1, const AT* A2, const AT* B2,
                       const ConvEpi& ep, hipStream_t st);
+bool conv_gemm_supports_gelu(const ConvGeom& g);   // ConvEpi::act == 1 may be requested for this geometry
 
 // ---------------------------------------------------------------- conv_wgrad.hip
 // dW[g][co][tap][kc] = sum_m dy[m][g*nc+co] * x[src(m,tap)][g*kc+kc], split over M.

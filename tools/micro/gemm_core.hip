@@ -347,7 +347,7 @@ float timeit(F f) {
 }
 
 int main() {
-  const int shapes[][3] = {{19600, 384, 1536}, {19600, 1536, 384}, {19600, 768, 1536}, {313600, 64, 256}, {313600, 128, 256}, {4900, 1536, 2304}};
+  const int shapes[][3] = {{19600, 384, 1536}, {19600, 1536, 384}, {19600, 768, 1536}, {19600, 3072, 384}, {78400, 512, 128}, {313600, 128, 256}, {4900, 1536, 2304}};
   for (auto& sh : shapes) {
     const int M = sh[0], K = sh[1], N = sh[2];
     std::vector<unsigned short> ha((size_t)M * K), hb((size_t)N * K);
@@ -399,6 +399,7 @@ int main() {
       vars.push_back({NAME, [=] { return timeit([=] { k_lds<BK, NS, LB, PF><<<grid, 256, shm>>>(A, B, C, M, N, K); }); }, 1e30f, true}); \
     }
     ADD_T(2, 2, 1, 3, "REGT 2x2 nb1") ADD_T(2, 2, 2, 2, "REGT 2x2 nb2") ADD_T(4, 2, 1, 2, "REGT 4x2 nb1")
+    ADD_T(4, 2, 1, 4, "REGT 4x2 lb4") ADD_T(2, 4, 1, 4, "REGT 2x4 lb4") ADD_T(4, 2, 1, 3, "REGT 4x2 lb3")
     ADD_TP(2, 2, 1, 3, 2, "REGT 2x2 pf2")  ADD_L(64, 2, 2, "LDS bk64 x2") ADD_LP(64, 2, 2, 1, "LDS bk64 x2 pf") ADD_L(32, 3, 3, "LDS bk32 x3")
     for (int round = 0; round < 3; ++round)
       for (auto& v : vars) { float t = v.run(); if (t < v.best) v.best = t; }

@@ -22,6 +22,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+CODE = {"x": 1, "h": 2, "f": 3, "g": 4}
+
+
 def rel(a, b):
     a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
     return float((a - b).norm() / (b.norm() + 1e-30))
@@ -83,6 +86,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--golden", nargs="+", default=["c2s", "k8"])
     ap.add_argument("--time", action="store_true")
+    ap.add_argument("--combos", nargs="*", default=None,
+                    help="pass assignments F B T-F T-B, e.g. xxxh gggg (x split bf16, h one bf16, g one fp16, f exact fp32); "
+                         "default: all 16 x/h combinations")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "mode_attribution.json"))
     a = ap.parse_args()
     rows = []
@@ -92,8 +98,9 @@ def main():
             e, ms = run(case, dtype, None, a.time)
             rows.append(dict(golden=name, mode=dtype, ms=ms, **e))
             print(json.dumps(rows[-1]), flush=True)
-        for combo in itertools.product("xh", repeat=4):       # F, B, T-F, T-B
-            passes = [1 if c == "x" else 2 for c in combo]
+        combos = a.combos if a.combos else ["".join(c) for c in itertools.product("xh", repeat=4)]
+        for combo in combos:                                   # F, B, T-F, T-B
+            passes = [CODE[c] for c in combo]
             e, ms = run(case, "bf16x2", passes, a.time)
             rows.append(dict(golden=name, mode="".join(combo), ms=ms, **e))
             print(json.dumps(rows[-1]), flush=True)

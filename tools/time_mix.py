@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 from multimodal_dataset_distillation_amd.engine import UnrollEngine  # noqa: E402
 from multimodal_dataset_distillation_amd.networks import student_move_normalised_targets, synthetic_expert_params  # noqa: E402
 
-CODE = {"x": 1, "h": 2, "f": 3}
+CODE = {"x": 1, "h": 2, "f": 3, "g": 4}
 
 
 def main():
