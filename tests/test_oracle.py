@@ -216,3 +216,48 @@ def test_vit_structural_anchors():
     assert fm.names[-2:] == ["model.norm.weight", "model.norm.bias"]
     x = torch.randn(3, 3, 32, 32)
     assert fm(x, flat_param=fm.flat_param()).shape == (3, 64)
+
+
+def test_squeeze_excite_gate_from_the_mid_channel_pooled_vector():
+    """The identity the engine's SE path rests on: conv3 of a NormFreeBlock is a
+    pointwise conv, hence linear, so the pooled conv3 output timm's SEModule starts from (oracle/nfnet_ref.py
+    SEModule.forward: `x.mean((2, 3))`) equals conv3's standardised weight applied to the pooled MID-channel
+    activation plus its bias -- and the gradient of any function of that pooled vector w.r.t. the mid activation is
+    the per-image vector W3^T pb / hw broadcast over the pixels."""
+    from oracle import nfnet_ref as nr
+    torch.manual_seed(0)
+    enc = nr.ImageEncoder("nfnet_tiny")
+    nr.randomize_like_trained(enc, 1)
+    blk = enc.model.stages[2][0]
+    conv3 = blk.conv3
+    n, c, h = 3, conv3.in_channels, 5
+    a = torch.randn(n, c, h, h, dtype=torch.float64).float().requires_grad_(True)
+    y = conv3(a)
+    p_ref = y.mean((2, 3))
+    w3 = conv3.standardized_weight().reshape(conv3.out_channels, c)
+    p_mid = a.mean((2, 3)) @ w3.t() + conv3.bias
+    assert torch.allclose(p_ref, p_mid, rtol=1e-5, atol=1e-6)
+    pb = torch.randn_like(p_ref)
+    ga, = torch.autograd.grad((p_ref * pb).sum(), a)
+    want = (pb @ w3 / (h * h))[:, :, None, None].expand_as(a)
+    assert torch.allclose(ga, want, rtol=1e-5, atol=1e-7)
+
+
+def test_goldens_are_present_and_well_formed():
+    """Every fixture the GPU suite compares against exists, loads without pickle, and holds finite numbers
+    (tests/golden/*.npz are written by oracle/gen_golden.py in the build container: the GPU box never sees the reference)."""
+    want = {"unroll_tiny": ["it0_grand", "it1_grand", "theta0_img", "perms"],
+            "unroll_c1_scalars": ["it0_grand", "it0_g_image_syn_slice", "it0_g_text_syn"],
+            "unroll_c2s_scalars": ["it0_grand", "it0_g_image_syn_slice", "it0_text_syn_after"],
+            "unroll_k8_scalars": ["it0_grand", "it0_ces", "it0_g_image_syn_slice", "it0_text_syn_after", "perms"],
+            "text_only_unroll": ["grand", "g_text_syn"], "itm_eval_small": ["rank_i2t"],
+            "nearest_neighbor_small": ["index"]}
+    for name, keys in want.items():
+        g = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+        for k in keys:
+            assert k in g.files, (name, k)
+            if g[k].dtype.kind == "f":
+                assert np.isfinite(g[k]).all(), (name, k)
+    k8 = np.load(os.path.join(GOLDEN, "unroll_k8_scalars.npz"))
+    assert (int(k8["n"]), int(k8["K"]), int(k8["size"]), str(k8["variant"])) == (12, 8, 224, "nfnet_l0")
+    assert k8["perms"].shape == (1, 8, 12) and k8["it0_ces"].shape == (8,) and 0.5 < float(k8["it0_grand"]) < 50
