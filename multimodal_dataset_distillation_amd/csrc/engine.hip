@@ -43,6 +43,11 @@ int mdd_set_error_msg(int code, const char* msg) {
 #ifndef MDD_SE_SIDE
 #define MDD_SE_SIDE 2            // forward passes: squeeze-excite gate chain beside conv3 -- 0: no (main stream),
 #endif                           // 1: on the side stream, 2: on a stream of its own with high queue priority
+#ifndef MDD_SE_W13
+#define MDD_SE_W13 0             // experiment (r03_experiments.md: +1 % time, rejected): squeeze-excite chain through
+                                 // W13 = W1 W3_hat (se_prep) -- one product fewer on the dependent chain, 24-48 more
+                                 // small products per pass off it; 0: p, h, gate / pb, qb in sequence
+#endif
 #ifndef MDD_VIT_FUSE_GELU
 #define MDD_VIT_FUSE_GELU 1      // ViT MLP: exact GELU (and its chain rule) in the epilogues of fc1 / fc2's data gradient
 #endif
@@ -542,6 +547,13 @@ struct Eng : mdd_engine {
       plan(&wslab[0], wslab_floats, nullptr, -2); plan(&wslab[1], wslab_floats, nullptr, -2);
     }
     plan(&ln_stats, (int64_t)N * 4, nullptr, -2);
+    // squeeze-excite shortcut operands, per block (se_prep): W13 = W1 W3_hat [rd, mid], b13 = W1 b3 + b1, tangents
+    se13.resize(blks.size());
+    for (size_t b = 0; b < blks.size(); ++b) {
+      const int64_t rm = (int64_t)blks[b].se.rd * blks[b].mid;
+      plan(&se13[b].W, rm, nullptr, -2); plan(&se13[b].W_t, rm, nullptr, -2);
+      plan(&se13[b].b, blks[b].se.rd, nullptr, -2); plan(&se13[b].b_t, blks[b].se.rd, nullptr, -2);
+    }
     plan(&lossw, loss_work_floats(N, feat), nullptr, -2);
     sets.resize(nslots);
     for (int k = 0; k < nslots; ++k) plan_set(sets[k], k);
@@ -652,6 +664,7 @@ struct Eng : mdd_engine {
     if (gstream) { (void)hipStreamSynchronize(gstream); (void)hipStreamDestroy(gstream); }
     for (auto e : evs) (void)hipEventDestroy(e);
     for (auto e : tf_ev) if (e) (void)hipEventDestroy(e);
+    if (se13_ev) (void)hipEventDestroy(se13_ev);
     for (auto& p : prof) { if (!p.shared_a) (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   }
   std::vector<hipEvent_t> evs;
@@ -1106,6 +1119,7 @@ struct Eng : mdd_engine {
     launch_ws_forward<AT>(d_descs, (int)descs.size(), total_rows, total_tiles, th, T ? th_t : nullptr, wf, wt,
                           wf_t, wt_t, st);
     if (!T) launch_img_gather_nhwc<AT>(P.X0, image, idx, N, 3, S, S, 8, st);
+    se_prep(T, th, th_t, st);
     tf_split_active = T && use_side && MDD_TF_SPLIT;
     if (tf_split_active) { tf_side_prepass(P, Q, st); tf_wait(0, st); }
     const AT* in = P.X0; const AT* in_t = nullptr;
@@ -1150,14 +1164,21 @@ struct Eng : mdd_engine {
         hipStream_t gs = st;
         if (use_side && MDD_SE_SIDE == 1) { fork(st); gs = side; sc_forked = true; }
         if (use_side && MDD_SE_SIDE == 2 && gstream) { fork_to(gstream, st); gs = gstream; g_forked = true; }
-        const ConvL& L3 = convs[B.c3];
+        se_prep_wait(gs);
         launch_pool_mean<AT>(T ? qa.q : pa.q, T ? qa.A2b : pa.A2b, N, hw, B.mid, gs);
-        launch_linear_fwd_w<AT>(pa.p, T ? qa.p : nullptr, pa.q, T ? qa.q : nullptr, wf + L3.off_p,
-                                T ? wf_t + L3.off_p : nullptr, th + L3.off_b, T ? th_t + L3.off_b : nullptr, N,
-                                B.mid, c, 1.f, gs);
-        launch_linear_fwd(pa.h, T ? qa.h : nullptr, pa.p, T ? qa.p : nullptr, th + B.se.off_w1,
-                          T ? th_t + B.se.off_w1 : nullptr, th + B.se.off_b1,
-                          T ? th_t + B.se.off_b1 : nullptr, N, c, rd, 1, lin_main, gs);
+        if (MDD_SE_W13) {
+          // h = relu(q W13^T + b13)  (= relu(W1 (W3_hat q + b3) + b1): one K = mid product instead of two)
+          launch_linear_fwd(pa.h, T ? qa.h : nullptr, pa.q, T ? qa.q : nullptr, se13[b].W, T ? se13[b].W_t : nullptr,
+                            se13[b].b, T ? se13[b].b_t : nullptr, N, B.mid, rd, 1, lin_main, gs);
+        } else {
+          const ConvL& L3 = convs[B.c3];
+          launch_linear_fwd_w<AT>(pa.p, T ? qa.p : nullptr, pa.q, T ? qa.q : nullptr, wf + L3.off_p,
+                                  T ? wf_t + L3.off_p : nullptr, th + L3.off_b, T ? th_t + L3.off_b : nullptr, N,
+                                  B.mid, c, 1.f, gs);
+          launch_linear_fwd(pa.h, T ? qa.h : nullptr, pa.p, T ? qa.p : nullptr, th + B.se.off_w1,
+                            T ? th_t + B.se.off_w1 : nullptr, th + B.se.off_b1,
+                            T ? th_t + B.se.off_b1 : nullptr, N, c, rd, 1, lin_main, gs);
+        }
         launch_linear_fwd(pa.gate, T ? qa.gate : nullptr, pa.h, T ? qa.h : nullptr, th + B.se.off_w2,
                           T ? th_t + B.se.off_w2 : nullptr, th + B.se.off_b2,
                           T ? th_t + B.se.off_b2 : nullptr, N, rd, c, 2, lin_main, gs);
@@ -1166,6 +1187,15 @@ struct Eng : mdd_engine {
       bool lastb = b == nb - 1;
       if (sc_forked) join(st);
       if (g_forked) join_from(gstream, st);
+      if (MDD_SE_W13) {
+        // p = q W3_hat^T + b3 (the pooled conv3 output itself) is only needed by the weight gradients of the backward
+        // passes: formed behind the gate (after the event the main stream waits for), off the dependent chain
+        hipStream_t ps = g_forked ? gstream : st;
+        const ConvL& L3 = convs[B.c3];
+        launch_linear_fwd_w<AT>(pa.p, T ? qa.p : nullptr, pa.q, T ? qa.q : nullptr, wf + L3.off_p,
+                                T ? wf_t + L3.off_p : nullptr, th + L3.off_b, T ? th_t + L3.off_b : nullptr, N,
+                                B.mid, c, 1.f, ps);
+      }
       launch_se_apply<AT>(pa.C3, T ? qa.C3 : nullptr, pa.gate, T ? qa.gate : nullptr, sc,
                           T ? sc_t : nullptr, P.X[b + 1], T ? Q.X[b + 1] : nullptr,
                           lastb ? nullptr : P.A[b + 1], (T && !lastb) ? Q.A[b + 1] : nullptr, ga,
@@ -1174,6 +1204,7 @@ struct Eng : mdd_engine {
     tf_wait(nb + 1, st);
     conv_fwd(T, convs[fin], P.X[nb], Q.X[nb], P.CF, Q.CF, nullptr, nullptr, 1.f, th, th_t, st);
     if (tf_split_active) { join(st); tf_split_active = false; }
+    if (use_side && gstream) join_from(gstream, st);     // the trailing p products of the gate stream
     int hwf = xh[nb] * xh[nb];
     launch_final_pool<AT>(P.y, T ? feat_out : nullptr, P.CF, T ? Q.CF : nullptr, N, hwf, feat, st);
     if (!T && feat_out && feat_out != P.y)
@@ -1194,9 +1225,12 @@ struct Eng : mdd_engine {
     ActSet& P = sets[slot]; ActSet& Q = tn;
     ActSet& O = (!T && !stash) ? tn : P;  // where primal backward signals are written
     int nb = (int)blks.size();
-    if (repack)
+    if (repack) {
       launch_ws_forward<AT>(d_descs, (int)descs.size(), total_rows, total_tiles, th, T ? th_t : nullptr, wf, wt,
                             wf_t, wt_t, st);
+      se_prep(T, th, th_t, st);
+    }
+    se_prep_wait(st);
     float* dw = O.dwf; float* dw_t = Q.dwf;
     // (no zero-fill of dwf: every conv's two-phase weight gradient overwrites its whole packed slice)
     HIP_CHECK_RET(hipMemsetAsync(gout, 0, P_img * 4, st));
@@ -1232,7 +1266,11 @@ struct Eng : mdd_engine {
         float *gw2 = gout + B.se.off_w2, *gb2 = gout + B.se.off_b2, *gw1 = gout + B.se.off_w1,
               *gb1 = gout + B.se.off_b1, *gw3 = (T ? dw_t : dw) + L3.off_p, *gb3 = gout + L3.off_b;
         const int n_ = N, mid_ = B.mid;
+        float *pBw = oa.pB, *pBw_t = T ? qa.pB : nullptr;
+        const float *W1 = th + B.se.off_w1, *W1_t = T ? th_t + B.se.off_w1 : nullptr;
         wq.push_back([=](hipStream_t ws_) {
+          // pb = hb W1 (gradient w.r.t. the pooled conv3 output): only the weight gradients need it
+          if (MDD_SE_W13) launch_linear_dgrad(pBw, pBw_t, hB, hB_t, W1, W1_t, nullptr, n_, c, rd, wlin(), ws_);
           launch_linear_wgrad(gw2, gb2, zB, zB_t, hh, hh_t, n_, rd, c, wlin(), ws_);
           launch_linear_wgrad(gw1, gb1, hB, hB_t, pp, pp_t, n_, c, rd, wlin(), ws_);
           // after conv3's own weight gradient (queued above: same stream, in order) has overwritten its slice
@@ -1242,10 +1280,16 @@ struct Eng : mdd_engine {
       launch_linear_dgrad(oa.hB, T ? qa.hB : nullptr, oa.zB, T ? qa.zB : nullptr,
                           th + B.se.off_w2, T ? th_t + B.se.off_w2 : nullptr, pa.h, N, rd, c,
                           lin_main, st);
-      launch_linear_dgrad(oa.pB, T ? qa.pB : nullptr, oa.hB, T ? qa.hB : nullptr, th + B.se.off_w1,
-                          T ? th_t + B.se.off_w1 : nullptr, nullptr, N, c, rd, lin_main, st);
-      launch_linear_fwd_w<AT>(oa.qB, T ? qa.qB : nullptr, oa.pB, T ? qa.pB : nullptr, wt + L3.off_p,
-                              T ? wt_t + L3.off_p : nullptr, nullptr, nullptr, N, c, B.mid, 1.f, st);
+      if (MDD_SE_W13) {
+        // qb = hb W13 (= (hb W1) W3_hat): the gradient w.r.t. the mid-channel pooled vector in ONE K = rd product
+        launch_linear_dgrad(oa.qB, T ? qa.qB : nullptr, oa.hB, T ? qa.hB : nullptr, se13[b].W, T ? se13[b].W_t : nullptr,
+                            nullptr, N, B.mid, rd, lin_main, st);
+      } else {
+        launch_linear_dgrad(oa.pB, T ? qa.pB : nullptr, oa.hB, T ? qa.hB : nullptr, th + B.se.off_w1,
+                            T ? th_t + B.se.off_w1 : nullptr, nullptr, N, c, rd, lin_main, st);
+        launch_linear_fwd_w<AT>(oa.qB, T ? qa.qB : nullptr, oa.pB, T ? qa.pB : nullptr, wt + L3.off_p,
+                                T ? wt_t + L3.off_p : nullptr, nullptr, nullptr, N, c, B.mid, 1.f, st);
+      }
       // residual branch
       {
         ConvEpi e3 = epi_act(T, oa.A2bB, oa.C2bB, qa.C2bB, pa.C2b, qa.C2b, 1.f, nullptr, nullptr);
@@ -1345,6 +1389,41 @@ struct Eng : mdd_engine {
     return 0;
   }
   std::vector<const float*> slot_mask_ = std::vector<const float*>(65, nullptr);
+
+  // ---- squeeze-excite shortcut (round 3).  h_pre = W1 (W3_hat q + b3) + b1 = W13 q + b13 with W13 = W1 W3_hat
+  // [rd, mid]: the dependent chain of a block is pool -> (K = mid) -> (K = rd) instead of pool -> (K = mid) -> (K = C)
+  // -> (K = rd), and in the backward passes qb = hb W13 replaces pb = hb W1, qb = pb W3_hat on the critical path (pb
+  // and p are still formed, off that path, for the weight gradients).  W13 / b13 depend on theta only: they are built
+  // on the gate stream at the start of every pass that (re)packs the weights, beside the stem.
+  struct Se13 { float *W = nullptr, *W_t = nullptr, *b = nullptr, *b_t = nullptr; };
+  std::vector<Se13> se13;
+  hipEvent_t se13_ev = nullptr;
+  void se_prep(bool T, const float* th, const float* th_t, hipStream_t st) {
+    if (!MDD_SE_W13) return;
+    hipStream_t s2 = (use_side && gstream) ? gstream : st;
+    fork_to(s2, st);                   // after ws_forward: the packed (transposed) conv3 weights exist
+    for (size_t b = 0; b < blks.size(); ++b) {
+      const Blk& B = blks[b]; const ConvL& L3 = convs[B.c3];
+      const int C = B.se.c, rd = B.se.rd, mid = B.mid;
+      const float *W1 = th + B.se.off_w1, *b1 = th + B.se.off_b1, *b3 = th + L3.off_b;
+      // primal always (a tangent pass follows a repack at ITS theta_k); rows of W1 play the role of the batch
+      launch_linear_fwd_w<AT>(se13[b].W, nullptr, W1, nullptr, wt + L3.off_p, nullptr, nullptr, nullptr, rd, C, mid, 1.f, s2);
+      launch_matvec_bias(se13[b].b, nullptr, W1, nullptr, b3, nullptr, b1, nullptr, rd, C, s2);
+      if (T) {
+        const float *W1_t = th_t + B.se.off_w1, *b1_t = th_t + B.se.off_b1, *b3_t = th_t + L3.off_b;
+        launch_linear_fwd_w<AT>(se13[b].W, se13[b].W_t, W1, W1_t, wt + L3.off_p, wt_t + L3.off_p, nullptr, nullptr, rd, C,
+                                mid, 1.f, s2);
+        launch_matvec_bias(nullptr, se13[b].b_t, W1, W1_t, b3, b3_t, nullptr, b1_t, rd, C, s2);
+      }
+    }
+    if (s2 != st) {
+      if (!se13_ev) ck(hipEventCreateWithFlags(&se13_ev, hipEventDisableTiming), "hipEventCreateWithFlags");
+      ck(hipEventRecord(se13_ev, s2), "hipEventRecord");
+    }
+  }
+  void se_prep_wait(hipStream_t s) {   // a stream about to read W13 / b13
+    if (se13_ev && use_side && gstream && s != gstream) ck(hipStreamWaitEvent(s, se13_ev, 0), "hipStreamWaitEvent");
+  }
 
   int txt_backward(bool T, int slot, const float* th, const float* th_t, const float* ybar_in,
                    const float* ybar_t_in, float* gout, float* dtext, const int64_t* idx,

@@ -193,6 +193,10 @@ void launch_linear_fwd_w(float* y, float* y_t, const float* x, const float* x_t,
 void launch_linear_wgrad_accum(float* dW, float* db, const float* dy, const float* dy_t, const float* x,
                                const float* x_t, int n, int k, int j, hipStream_t st);
 
+// out[j] = sum_c W[j,c] v[c] + b[j] (primal: out_t == null); tangent call writes out_t only
+void launch_matvec_bias(float* out, float* out_t, const float* W, const float* W_t, const float* v, const float* v_t,
+                        const float* b, const float* b_t, int rows, int cols, hipStream_t st);
+
 // ---------------------------------------------------------------- retrieval.hip (fp32)
 // scores[b,n] = scale * <img_hat[i], txt_hat[j]> ; rank_i2t[i], rank_t2i[j] (see retrieval.hip).
 // img2txt as CSR (off[b+1], idx[]); rn_ws: b + n floats of scratch.

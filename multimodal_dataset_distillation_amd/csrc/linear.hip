@@ -557,3 +557,29 @@ void launch_linear_wgrad_accum(float* dW, float* db, const float* dy, const floa
   run_lin_mfma<float>(tangent, dy, dy_t, x, x_t, dW, j, k, n, 1, j, k, 1, EP_PLAIN, 0, nullptr, nullptr, db, 1, 1.f,
                       st);
 }
+
+// out[j] = sum_c W[j,c] v[c] + b[j]   (tangent: out_t[j] = sum_c (W_t[j,c] v[c] + W[j,c] v_t[c]) + b_t[j]); a wave per row
+__global__ __launch_bounds__(256) void k_matvec_bias(float* __restrict__ out, float* __restrict__ out_t,
+                                                     const float* __restrict__ W, const float* __restrict__ W_t,
+                                                     const float* __restrict__ v, const float* __restrict__ v_t,
+                                                     const float* __restrict__ b, const float* __restrict__ b_t, int rows,
+                                                     int cols) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float a = 0.f, at = 0.f;
+  for (int c = lane; c < cols; c += 64) {
+    const float w = W[(size_t)row * cols + c], x = v[c];
+    a += w * x;
+    if (out_t) at += (W_t ? W_t[(size_t)row * cols + c] : 0.f) * x + w * (v_t ? v_t[c] : 0.f);
+  }
+  a = wave_sum(a);
+  if (out_t) at = wave_sum(at);
+  if (lane == 0) {
+    if (out_t) out_t[row] = at + (b_t ? b_t[row] : 0.f);
+    else out[row] = a + (b ? b[row] : 0.f);
+  }
+}
+void launch_matvec_bias(float* out, float* out_t, const float* W, const float* W_t, const float* v, const float* v_t,
+                        const float* b, const float* b_t, int rows, int cols, hipStream_t st) {
+  k_matvec_bias<<<(rows + 3) / 4, 256, 0, st>>>(out, out_t, W, W_t, v, v_t, b, b_t, rows, cols);
+}
