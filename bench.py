@@ -159,6 +159,12 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29531"),
                os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
+    # ONE JSON line on stdout, whatever the libraries underneath print: RCCL writes a version banner to the process's
+    # stdout when a communicator is created (seen with `--collective library`; torch's own nccl backend initialises one
+    # lazily at N > 1).  From here on file descriptor 1 points at stderr; the result line goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0)) % max(1, torch.cuda.device_count())
@@ -554,7 +560,8 @@ def main():
                 others[name] = {"error": repr(ex)[:400]}
         result["other_workloads"] = others
     if rank == 0:
-        print(json.dumps(result))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
     if libcoll is not None:
         libcoll.close()       # ncclCommDestroy before torch's process group goes away
     if world > 1:
