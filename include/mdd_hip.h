@@ -261,6 +261,19 @@ typedef struct mdd_bgemm_desc {
   int64_t a_outer, a_inner, b_outer, b_inner, c_outer, c_inner;   /* batch strides in elements */
   float alpha;
 } mdd_bgemm_desc;
+/* Fused multi-head attention of the bf16 ViT path (csrc/attn.hip): head dimension 64, tokens <= 224; qkv is the fused
+ * [n, tokens, 3, heads, 64] tensor, dout / out the [n, tokens, heads, 64] attention output (modes 0, 1) or, for the
+ * gradient modes, out = d qkv in qkv's layout.  Nothing of size tokens x tokens leaves the CU: every mode recomputes
+ * the score tiles it needs and exchanges per-row statistics [n, heads, tokens] (m, l: softmax max / sum, written by
+ * mode 0; r = rowsum(P S_t), written by mode 1; D = rowsum(P dP) = rowsum(O dO), by mode 2 from o and dout; D_t, by
+ * mode 3 from o, o_t, dout, dout_t).
+ *   0  O = softmax(scale Q K^T) V          1  O_t (tangent along qkv_t)          2  dQ = dS K      (r_tan: dS K_t, accum)
+ *   3  dQ_t part: dS_t K                   4  dV = P^T dO, dK = dS^T Q           (r_tan: dS^T Q_t; skip0: dK part only; accum)
+ *   5  dV_t = P_t^T dO + P^T dO_t          6  dK_t part: dS_t^T Q
+ * A full tangent of the backward is 3, 2(r_tan, accum), 5, 6, 4(r_tan, skip0, accum) on d qkv_t. */
+int mdd_op_attention(int mode, int n, int tokens, int heads, float scale, const void* qkv, const void* qkv_t,
+                     const void* dout, const void* dout_t, const void* o, const void* o_t, void* out, float* m, float* l,
+                     float* r, float* D, float* D_t, int r_tan, int accum, int skip0, void* stream);
 int mdd_op_layernorm(int dtype, int rows, int dim, float eps, const void* x, const void* x_t, const float* gamma,
                      const float* gamma_t, const float* beta, const float* beta_t, void* y, void* y_t, void* stream);
 int mdd_op_layernorm_bwd(int dtype, int rows, int dim, float eps, const void* x, const void* x_t, const void* dy,

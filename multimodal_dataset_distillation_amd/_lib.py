@@ -79,6 +79,7 @@ SIGNATURES = {
     "mdd_op_layernorm_bwd": (_I, [_I, _I, _I, _F] + [_P] * 15),
     "mdd_op_gelu": (_I, [_I, _L] + [_P] * 5),
     "mdd_op_gelu_bwd": (_I, [_I, _L] + [_P] * 7),
+    "mdd_op_attention": (_I, [_I, _I, _I, _I, _F] + [_P] * 12 + [_I, _I, _I, _P]),
     "mdd_op_softmax": (_I, [_I, _L, _I, _I, _F] + [_P] * 5),
     "mdd_op_softmax_bwd": (_I, [_I, _L, _I, _I, _F] + [_P] * 7),
     "mdd_op_bgemm": (_I, [_I, _I, _I] + [_P] * 8),

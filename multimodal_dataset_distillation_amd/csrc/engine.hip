@@ -48,6 +48,9 @@ int mdd_set_error_msg(int code, const char* msg) {
                                  // W13 = W1 W3_hat (se_prep) -- one product fewer on the dependent chain, 24-48 more
                                  // small products per pass off it; 0: p, h, gate / pb, qb in sequence
 #endif
+#ifndef MDD_VIT_FUSED_ATTENTION
+#define MDD_VIT_FUSED_ATTENTION 1   // bf16 ViT: attention through csrc/attn.hip (0: bgemm + softmax kernels, scores in HBM)
+#endif
 #ifndef MDD_VIT_FUSE_GELU
 #define MDD_VIT_FUSE_GELU 1      // ViT MLP: exact GELU (and its chain rule) in the epilogues of fc1 / fc2's data gradient
 #endif
@@ -184,6 +187,7 @@ template <class AT>
 struct Eng : mdd_engine {
   NfCfg nf;
   bool is_vit = false;     // the image encoder is a Vision Transformer (vit_forward / vit_backward below)
+  bool fused_attn = false; // bf16 ViT with head dimension 64 and <= 224 tokens: attention by attn.hip, no score-sized tensors
   VitCfg vit;
   int Tk = 0, sld = 0;     // tokens per image (1 + patches), row stride of the score / probability matrices
   std::vector<VitBlkL> vblk;
@@ -233,6 +237,7 @@ struct Eng : mdd_engine {
     AT* P;                                    // attention probabilities [batch*heads*tokens, sld], in the storage type
     AT *N1B, *QKVB, *OB, *X2B, *N2B, *CB, *AB;
     AT *PB, *SB;                              // gradients of the probabilities / of the scores
+    float *sm, *sl, *sr, *sD, *sDt;           // fused attention (attn.hip): per-row statistics [batch, heads, tokens]
   };
   struct ActSet {
     AT *VCOL = nullptr, *VPE = nullptr, *VCOLB = nullptr, *VPEB = nullptr;   // patch columns, patch embedding (+ grads)
@@ -321,6 +326,7 @@ struct Eng : mdd_engine {
       const int D = vit.dim, gp = S / vit.patch;
       Tk = 1 + gp * gp; sld = (Tk + 7) & ~7;
       CHECK_ARG(D % vit.heads == 0 && Tk <= 512, "heads must divide dim; at most 512 tokens");
+      fused_attn = MDD_VIT_FUSED_ATTENTION && sizeof(AT) == 2 && attention_fused_supported(Tk, D / vit.heads);
       auto add_lin = [&](const std::string& name, int cin, int cout, int tokens, bool conv_shape) {
         ConvL L; L.cin = cin; L.cout = cout; L.k = 1; L.stride = 1; L.groups = 1; L.pad = 0;
         L.hin = 1; L.hout = 1; L.cin_pad = cin; L.tokens = tokens;
@@ -454,11 +460,18 @@ struct Eng : mdd_engine {
       VitActs& a = s.vb[l];
       std::string p = "v" + std::to_string(l) + ".";
       plan(&a.N1, M * D, (p + "N1").c_str(), slot);   plan(&a.QKV, M * 3 * D, (p + "QKV").c_str(), slot);
-      plan(&a.P, pr, (p + "P").c_str(), slot);        plan(&a.O, M * D, (p + "O").c_str(), slot);
+      if (!fused_attn) plan(&a.P, pr, (p + "P").c_str(), slot); else a.P = nullptr;
+      plan(&a.O, M * D, (p + "O").c_str(), slot);
       plan(&a.X2, M * D, (p + "X2").c_str(), slot);   plan(&a.N2, M * D, (p + "N2").c_str(), slot);
       plan(&a.C, M * 4 * D, (p + "C").c_str(), slot); plan(&a.A, M * 4 * D, (p + "A").c_str(), slot);
       plan(&a.N1B, M * D, (p + "N1B").c_str(), slot); plan(&a.QKVB, M * 3 * D, (p + "QKVB").c_str(), slot);
-      plan(&a.PB, pr, (p + "PB").c_str(), slot);      plan(&a.SB, pr, (p + "SB").c_str(), slot);
+      if (!fused_attn) { plan(&a.PB, pr, (p + "PB").c_str(), slot); plan(&a.SB, pr, (p + "SB").c_str(), slot); }
+      else {
+        a.PB = a.SB = nullptr;
+        const int64_t ns = n * vit.heads * Tk;
+        plan(&a.sm, ns, nullptr, slot); plan(&a.sl, ns, nullptr, slot); plan(&a.sr, ns, nullptr, slot);
+        plan(&a.sD, ns, nullptr, slot); plan(&a.sDt, ns, nullptr, slot);
+      }
       plan(&a.OB, M * D, (p + "OB").c_str(), slot);   plan(&a.X2B, M * D, (p + "X2B").c_str(), slot);
       plan(&a.N2B, M * D, (p + "N2B").c_str(), slot); plan(&a.CB, M * 4 * D, (p + "CB").c_str(), slot);
       plan(&a.AB, M * 4 * D, (p + "AB").c_str(), slot);
@@ -967,7 +980,13 @@ struct Eng : mdd_engine {
       // backward kernel applied to the score tangent.
       const AT *q = pa.QKV, *k = pa.QKV + D, *v = pa.QKV + 2 * D;
       const AT *q_t = T ? qa.QKV : nullptr, *k_t = T ? qa.QKV + D : nullptr, *v_t = T ? qa.QKV + 2 * D : nullptr;
-      if (!T) {
+      if (fused_attn) {
+        // one launch: the score tiles are recomputed on the matrix cores, only O (O_t) and the row statistics leave the CU
+        if (!T) VIT_RC(launch_attention(0, pa.QKV, nullptr, nullptr, nullptr, pa.O, nullptr, nullptr, pa.sm, pa.sl, nullptr, nullptr,
+                                        nullptr, N, Tk, vit.heads, scale, 0, 0, 0, st));
+        else VIT_RC(launch_attention(1, pa.QKV, qa.QKV, nullptr, nullptr, qa.O, nullptr, nullptr, pa.sm, pa.sl, qa.sr, nullptr, nullptr,
+                                     N, Tk, vit.heads, scale, 0, 0, 0, st));
+      } else if (!T) {
         VIT_RC(mdd_op_bgemm(bdt(), 0, 0, &ad.s, q, nullptr, k, nullptr, pa.P, nullptr, st));
         VIT_RC(mdd_op_softmax(VDT, rows, Tk, sld, scale, pa.P, nullptr, pa.P, nullptr, st));
         VIT_RC(mdd_op_bgemm(bdt(), 0, 0, &ad.o, pa.P, nullptr, v, nullptr, pa.O, nullptr, st));
@@ -1067,7 +1086,28 @@ struct Eng : mdd_engine {
       lin_bwd_w(T, convs[B.proj], oa.X2B, qa.X2B, pa.O, qa.O, gout, st);
       conv_bwd_d(T, convs[B.proj], oa.X2B, qa.X2B, epi_lin(T ? qa.OB : oa.OB, nullptr), st);
       const AT *q = pa.QKV, *k = pa.QKV + D, *v = pa.QKV + 2 * D;
-      if (!T) {
+      if (fused_attn) {
+        const int H_ = vit.heads;
+        if (!T) {
+          // d qkv = (dS K | dS^T Q | P^T dO): query-owner launch (writes D = rowsum(P dP)), then the key-owner one
+          VIT_RC(launch_attention(2, pa.QKV, nullptr, oa.OB, nullptr, oa.QKVB, pa.O, nullptr, pa.sm, pa.sl, nullptr, oa.sD, nullptr,
+                                  N, Tk, H_, scale, 0, 0, 0, st));
+          VIT_RC(launch_attention(4, pa.QKV, nullptr, oa.OB, nullptr, oa.QKVB, nullptr, nullptr, pa.sm, pa.sl, nullptr, oa.sD, nullptr,
+                                  N, Tk, H_, scale, 0, 0, 0, st));
+        } else {
+          // tangent: dQ_t = dS_t K + dS K_t ; dV_t = P_t^T dO + P^T dO_t ; dK_t = dS_t^T Q + dS^T Q_t
+          VIT_RC(launch_attention(3, pa.QKV, qa.QKV, oa.OB, qa.OB, qa.QKVB, pa.O, qa.O, pa.sm, pa.sl, qa.sr, oa.sD, qa.sDt, N, Tk,
+                                  H_, scale, 0, 0, 0, st));
+          VIT_RC(launch_attention(2, pa.QKV, qa.QKV, oa.OB, nullptr, qa.QKVB, pa.O, nullptr, pa.sm, pa.sl, nullptr, qa.sD, nullptr, N,
+                                  Tk, H_, scale, 1, 1, 0, st));
+          VIT_RC(launch_attention(5, pa.QKV, qa.QKV, oa.OB, qa.OB, qa.QKVB, nullptr, nullptr, pa.sm, pa.sl, qa.sr, nullptr, nullptr, N, Tk,
+                                  H_, scale, 0, 0, 0, st));
+          VIT_RC(launch_attention(6, pa.QKV, qa.QKV, oa.OB, qa.OB, qa.QKVB, nullptr, nullptr, pa.sm, pa.sl, qa.sr, oa.sD, qa.sDt, N, Tk,
+                                  H_, scale, 0, 0, 0, st));
+          VIT_RC(launch_attention(4, pa.QKV, qa.QKV, oa.OB, nullptr, qa.QKVB, nullptr, nullptr, pa.sm, pa.sl, nullptr, oa.sD, nullptr, N,
+                                  Tk, H_, scale, 1, 1, 1, st));
+        }
+      } else if (!T) {
         AT* z = oa.QKVB;
         VIT_RC(mdd_op_bgemm(bdt(), 0, 0, &ad.dp, oa.OB, nullptr, v, nullptr, oa.PB, nullptr, st));
         VIT_RC(mdd_op_softmax_bwd(VDT, rows, Tk, sld, scale, pa.P, nullptr, oa.PB, nullptr, oa.SB, nullptr, st));

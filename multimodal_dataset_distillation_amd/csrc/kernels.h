@@ -262,3 +262,11 @@ template <class AT> void launch_lin_pack(AT* wf, AT* wt, const float* w, int out
 struct LinPackDesc { int64_t off_w, off_p; int out, in, tile_start, pad_; };
 template <class AT> void launch_lin_pack_all(const LinPackDesc* descs, int nd, int total_tiles, const float* th, const float* th_t,
                                              AT* wf, AT* wt, AT* wf_t, AT* wt_t, hipStream_t st);
+
+// ---------------------------------------------------------------- attn.hip (bf16; fused attention of the ViT path)
+// mode: 0 O = P V (writes m, l; optionally P) | 1 O_t (reads m, l; writes r) | 2 dQ = dS K (writes D; r_tan: K_t,
+// accum) | 3 dS_t K (reads r, D; writes D_t) | 4 dV = P^T dO, dK = dS^T Q (r_tan: Q_t; skip0; accum) | 5 dV_t | 6 dS_t^T Q
+int launch_attention(int mode, const void* qkv, const void* qkv_t, const void* dout, const void* dout_t, void* out,
+                     const void* o, const void* o_t, float* m, float* l, float* r, float* D, float* D_t, int n, int tokens,
+                     int heads, float scale, int r_tan, int accum, int skip0, hipStream_t st);
+bool attention_fused_supported(int tokens, int head_dim);
