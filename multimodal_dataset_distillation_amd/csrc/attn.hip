@@ -217,11 +217,16 @@ __global__ __launch_bounds__(512, 2) void k_attn(const AttnArgs p) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
   };
   // score-type tile t: acc[r] = sum_d Y[32 t + rowmap(r, lh)][d] * U[own][d]
-  auto tile = [&](const char* Y, const u32x4* fU, int t, f32x16& acc) {
+  auto tile = [&](const char* Y, const u32x4* fU, int t, f32x16& acc, bool first) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const u32x4 a = *(const u32x4*)(Y + lds_row_off(32 * t + l31, 2 * s + lh));
-      mm(a, fU[s], acc);
+      if (first && s == 0) {        // the product starts from the constant 0 (no register zero-fill per tile)
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, fU[s]), z, 0, 0, 0);
+      } else {
+        mm(a, fU[s], acc);
+      }
     }
   };
   struct Tiles { f32x16 S, St, dP, dPt; };
@@ -230,11 +235,11 @@ __global__ __launch_bounds__(512, 2) void k_attn(const AttnArgs p) {
     for (int r = 0; r < 16; ++r) a[r] = 0.f;
   };
   auto compute_tiles = [&](int t, Tiles& X) {
-    zero(X.S); tile(Y1, fU1, t, X.S);
-    if constexpr (TAN) { zero(X.St); tile(Y1t, fU1, t, X.St); tile(Y1, fU1t, t, X.St); }
+    tile(Y1, fU1, t, X.S, true);
+    if constexpr (TAN) { tile(Y1t, fU1, t, X.St, true); tile(Y1, fU1t, t, X.St, false); }
     if constexpr (DP) {
-      zero(X.dP); tile(Y2, fU2, t, X.dP);
-      if constexpr (TAN) { zero(X.dPt); tile(Y2t, fU2, t, X.dPt); tile(Y2, fU2t, t, X.dPt); }
+      tile(Y2, fU2, t, X.dP, true);
+      if constexpr (TAN) { tile(Y2t, fU2, t, X.dPt, true); tile(Y2, fU2t, t, X.dPt, false); }
     }
   };
   auto dot8 = [](const u32x4& a, const u32x4& b) {     // sum of the eight bf16 products of two 16-byte fragments
@@ -336,6 +341,8 @@ __global__ __launch_bounds__(512, 2) void k_attn(const AttnArgs p) {
 #pragma unroll UNR
   for (int t = 0; t < ((MDD_ATTN_DBG & 2) ? 0 : nt); ++t) {
     Tiles X; compute_tiles(t, X);
+    const float4* const sp4 = st4 + 32 * t + 4 * lh;     // statistics of query row 32 t + rowmap(r, lh): sp4[rowmap(r, 0)]
+    const float* const spD = stDt + 32 * t + 4 * lh;
     if constexpr (OQ) {
       if (32 * t + 32 > T) {           // partial tile: the padded keys must not count (block-uniform branch): S := -inf
 #pragma unroll
@@ -351,10 +358,9 @@ __global__ __launch_bounds__(512, 2) void k_attn(const AttnArgs p) {
         const int r = 8 * h + i;
         float nm_ = q_nm, li = q_linv, r_ = q_r, D_ = q_D, Dt_ = q_Dt;
         if constexpr (!OQ) {        // the query is the OTHER index: its statistics come from LDS (1/l = 0 beyond the tokens)
-          const int x = 32 * t + rowmap(r, lh);
-          const float4 v = st4[x];
+          const float4 v = sp4[rowmap(r, 0)];
           nm_ = v.x; li = v.y; r_ = v.z; D_ = v.w;
-          if constexpr (MODE == 6) Dt_ = stDt[x];
+          if constexpr (MODE == 6) Dt_ = spD[rowmap(r, 0)];
         }
         float P = __builtin_amdgcn_exp2f(fmaf(X.S[r], c1, nm_));
         if constexpr (MODE == 0) l_run += P; else P *= li;
@@ -398,29 +404,49 @@ __global__ __launch_bounds__(512, 2) void k_attn(const AttnArgs p) {
     }
   }
 
-  // ---- store: out[owner row 32 w + rowmap(r, lh)][32 dt + l31]
-  auto store = [&](const f32x16 (&acc)[2], bf16* dst, size_t stride, bool accum) {
+  // ---- store.  The accumulators hold out[owner row 32 w + rowmap(r, lh)][32 dt + l31]: one 2-byte element per lane and
+  // register.  They go through this wave's 4 KB of LDS (the row-major regions are free once every wave has left the tile
+  // loop) so that global memory sees 16-byte chunks: 4 store instructions per wave and output instead of 32.
+  __syncthreads();
+  auto store = [&](const f32x16 (&acc)[2], char* region, bf16* dst, size_t stride, bool accum) {
+    if (wave >= NT) return;                               // rows >= TP: never tokens
+    unsigned short* stg16 = (unsigned short*)(region + wave * 4096);
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = wave * 32 + rowmap(r, lh);
-        if (row < T && !(MDD_ATTN_DBG & 4)) {
-          bf16* q = dst + (size_t)row * stride + 32 * dt + l31;
-          float v = acc[dt][r];
-          if (accum) v += (float)*q;
-          *q = (bf16)v;
-        }
+        const bf16 v = (bf16)acc[dt][r];
+        stg16[rowmap(r, lh) * 64 + 32 * dt + l31] = __builtin_bit_cast(unsigned short, v);
       }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): this wave's LDS stores have landed
+    __builtin_amdgcn_wave_barrier();
+    if (MDD_ATTN_DBG & 4) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = lane + 64 * j, row = c >> 3, ch = c & 7, grow = wave * 32 + row;
+      if (grow < T) {
+        uint4 v = *(const uint4*)((const char*)stg16 + row * 128 + ch * 16);
+        bf16* q = dst + (size_t)grow * stride + ch * 8;
+        if (accum) {
+          float a[8], b[8];
+          Chunk<bf16>::unpack(v, a);
+          Chunk<bf16>::unpack(*(const uint4*)q, b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] += b[e];
+          v = Chunk<bf16>::pack(a);
+        }
+        *(uint4*)q = v;
+      }
+    }
   };
   if constexpr (MODE <= 1) {
-    store(o[0], p.out + (size_t)img * T * Dm + (size_t)head * HD, Dm, false);
+    store(o[0], Y1, p.out + (size_t)img * T * Dm + (size_t)head * HD, Dm, false);
   } else {
     bf16* dq = p.out + (size_t)img * T * qrow + (size_t)head * HD;
-    if constexpr (MODE == 2 || MODE == 3) store(o[0], dq + cq, qrow, p.accum != 0);
-    else if constexpr (MODE == 4) { if (!p.skip0) store(o[0], dq + cv, qrow, false); store(o[1], dq + ck, qrow, p.accum != 0); }
-    else if constexpr (MODE == 5) store(o[0], dq + cv, qrow, false);
-    else store(o[0], dq + ck, qrow, false);
+    if constexpr (MODE == 2 || MODE == 3) store(o[0], Y1, dq + cq, qrow, p.accum != 0);
+    else if constexpr (MODE == 4) { if (!p.skip0) store(o[0], Y1, dq + cv, qrow, false); store(o[1], Y2, dq + ck, qrow, p.accum != 0); }
+    else if constexpr (MODE == 5) store(o[0], Y1, dq + cv, qrow, false);
+    else store(o[0], Y1, dq + ck, qrow, false);
   }
 }
 
