@@ -67,7 +67,7 @@ const char* mdd_last_error(void);
 /* ABI version of this header: 2 = round 2 (mdd_config.keep_steps, MDD_DTYPE_BF16X2 / _F32_BF16OPS,
  * profile kind 4); 3 = + mdd_comm_* / mdd_allreduce_syn_grads; 4 = + the ViT building-block ops; 5 = + mdd_engine_set_pass_precision.  A binding built against another version
  * must refuse to load. */
-#define MDD_ABI_VERSION 5
+#define MDD_ABI_VERSION 6
 int mdd_version(void);
 
 /* ---- engine lifetime and memory (the caller owns device memory: PyTorch caching allocator) */
@@ -197,6 +197,14 @@ int mdd_op_conv2d(int dtype, int transposed, int nimg, int hin, int win, int cin
 int mdd_op_conv2d_wgrad(int dtype, int nimg, int hin, int win, int cin, int cout, int k, int stride,
                         int pad, int groups, const void* dy_dev, const void* x_dev,
                         float* dw_packed_dev, float* dbias_dev, void* stream);
+/* the engine's form of the weight gradient: an optional second pair (tangent pass: dW_t = dy1^T x1 + dy2^T x2) and
+ * a split-M workspace of ws_floats floats (partial tiles are summed by a second kernel into dw, which is then
+ * OVERWRITTEN; without a workspace the partials are added into dw with fp32 atomics).  The bias gradient is the
+ * column sum of dy1 (added into dbias). */
+int mdd_op_conv2d_wgrad2(int dtype, int nimg, int hin, int win, int cin, int cout, int k, int stride,
+                         int pad, int groups, const void* dy1_dev, const void* x1_dev, const void* dy2_dev,
+                         const void* x2_dev, float* dw_packed_dev, float* dbias_dev, float* ws_dev,
+                         long long ws_floats, void* stream);
 
 /* ---- synthetic-set evaluation: retrieval ranks.
  * Replaces the per-row host loops of reference epoch.py:140-156 (image->text: argsort of one similarity

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmdd_hip.so")
 
 DTYPE_F32, DTYPE_BF16, DTYPE_BF16X2, DTYPE_F32_BF16OPS = 0, 1, 2, 3
-ABI_VERSION = 5     # include/mdd_hip.h MDD_ABI_VERSION
+ABI_VERSION = 6     # include/mdd_hip.h MDD_ABI_VERSION
 
 
 class MddConfig(C.Structure):
@@ -66,6 +66,7 @@ SIGNATURES = {
     "mdd_unrolled_match": (_I, [_P, C.POINTER(MddIterArgs), _P]),
     "mdd_op_conv2d": (_I, [_I] * 11 + [_P, _P, _P, _P, _P]),
     "mdd_op_conv2d_wgrad": (_I, [_I] * 10 + [_P, _P, _P, _P, _P]),
+    "mdd_op_conv2d_wgrad2": (_I, [_I] * 10 + [_P] * 7 + [C.c_longlong, _P]),
     "mdd_op_contrastive_workspace_floats": (_L, [_I, _I]),
     "mdd_op_contrastive": (_I, [_I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P]),
     "mdd_retrieval_ranks": (_I, [_P] * 5 + [_I] * 3 + [C.c_float] + [_P] * 5),

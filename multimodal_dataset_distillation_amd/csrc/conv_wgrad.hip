@@ -22,6 +22,7 @@
 // are four CONSECUTIVE k' of one output channel = one 16-byte store.  An optional second pair (dy2, x2) is accumulated too (tangent pass), and the bias
 // gradient (column sums of dy1) is taken from the staging registers of the k'-tile-0 blocks.
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <type_traits>
 #include <cstdlib>
@@ -36,6 +37,15 @@
 #endif
 #ifndef MDD_WG_MIN_WAVES
 #define MDD_WG_MIN_WAVES 1
+#endif
+#ifndef MDD_WG_PIPE_MIN
+#define MDD_WG_PIPE_MIN 512  // narrowest layer (channels in and out) taken by the 256 x 256 pipelined kernel
+#endif
+#ifndef MDD_WGP_ABL
+#define MDD_WGP_ABL 0   // timing experiments on k_wgrad_pipe (wrong results): 1 no MFMAs, 2 no LDS-DMA, 4 no fragment reads, 8 no write-out
+#endif
+#ifndef MDD_WGP_SLOTS
+#define MDD_WGP_SLOTS 8    // half-tile slots of k_wgrad_pipe's LDS ring (16 KB each); half-tiles are issued SLOTS-2 phases ahead
 #endif
 #ifndef MDD_WG_BKM
 #define MDD_WG_BKM 64      // pixels per K-step of the bf16 instances
@@ -478,6 +488,330 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(float* __restrict__ dW, co
   }
 }
 
+// ======================================================================================================
+// Wide pointwise layers in bf16 (the ViT linears: 19,700 token rows onto 768..3072 x 768..3072 weights): a
+// 256 (co) x 256 (k') output tile per 512-thread block, one block per CU.
+//   * 8 waves as 2 (co) x 4 (k'), wave tile 128 x 64 = 8 x 4 accumulator blocks of v_mfma_f32_16x16x32_bf16
+//   * a K-tile = 64 pixels = four HALF-TILES of 64 rows x 256 B (16 KB): D0, X0, X1, D1.  D_h holds channels
+//     [64h, 64h+64) of BOTH wave rows, X_h columns [32h, 32h+32) of all four wave columns: every wave needs the
+//     half-tiles in the same order.  They live in an 8-slot LDS ring (128 KB) filled by global_load_lds_dwordx4
+//     -- no staging registers, no ds_write -- six phases ahead of their use; the chunk swizzle of the one-stage
+//     kernel is applied on the SOURCE address (the hardware writes lane-linear).  Pixels past the block's chunk
+//     and channels past the tensor read a block of zeros.
+//   * a K-tile is four PHASES: {ds_read_b64_tr_b16 this phase's fragments, issue one half-tile, counted vmcnt}
+//     barrier {16 MFMAs: one 64 x 32 quadrant x 64 pixels} barrier.  Wave row 1 runs ONE barrier behind wave
+//     row 0, so of the two waves of a SIMD one issues MFMAs while the other reads LDS.
+//   Hazards (g = phase index; both wave rows counted): a slot is read in ONE phase g_r and refilled by the
+//   issue of phase g_r + 2 or later (the lagging row's reads are retired by its lgkmcnt(0) two barriers before);
+//   a half-tile is read one phase after the phase whose vmcnt retired it (the lagging row's wait precedes the
+//   barrier the leading row passes before reading).
+// tools/micro/gemm_pipe.hip holds the same schedule on K-contiguous operands with its timings.
+__device__ __attribute__((aligned(16))) const unsigned g_wzero[64] = {0};
+
+template <int N_> DEVI void wait_vm() {
+  __builtin_amdgcn_s_waitcnt((N_ & 0xF) | ((N_ >> 4) << 14) | (0x7 << 4) | (0xF << 8));
+}
+DEVI void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+constexpr int WGP_NS = MDD_WGP_SLOTS, WGP_D = WGP_NS - 2;   // ring slots, issue distance in phases (see "Hazards")
+__global__ __launch_bounds__(512, 1) void k_wgrad_pipe(const WArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NS = WGP_NS, D = WGP_D;
+  const ConvGeom& G = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wc = wave >> 2, wk = wave & 3;
+  int bid, bsplit;
+  {
+    const int nwg = gridDim.x * gridDim.y, orig = blockIdx.x + blockIdx.y * gridDim.x;
+    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    bsplit = lin / gridDim.x;
+    bid = lin - bsplit * gridDim.x;
+  }
+  const int kpt = bid % p.kptiles, cot = bid / p.kptiles;
+  const int co0 = cot * 256, kp0 = kpt * 256;
+  const int ktot = G.kc;
+  const int mbeg = bsplit * p.mchunk;
+  const int mend = min(p.M, mbeg + p.mchunk);
+  const int rows = mend - mbeg;
+  const int nk1 = (rows + 63) >> 6;
+  const int nk = p.dy2 ? 2 * nk1 : nk1;
+  const int H = 4 * nk;
+
+  // ---- loader: two 1-KB wave instructions per half-tile; instruction j covers pixel rows j*32 + wave*4 + (lane>>4),
+  // this lane's 16-byte slot lane&15 of the row receives the chunk (slot ^ swizzle(row)) of the half-tile's 128 columns
+  // (both instructions and both halves share one offset: rows 32 apart have the same swizzle, halves are 64 / 32 columns apart)
+  const int lrow0 = wave * 4 + (lane >> 4);
+  const int lcidx = (lane & 15) ^ ((lrow0 & 7) << 1);
+  const int dch0 = co0 + lcidx * 8;       // channel of half 0; half 1 is + 128: every half-tile row is ONE 256-byte segment
+  const int xkk0 = kp0 + lcidx * 8;
+  const unsigned dv0 = (unsigned)((lrow0 * G.co_tot + dch0) * 2), xv0 = (unsigned)((lrow0 * G.ca_tot + xkk0) * 2);
+  const unsigned drow32 = (unsigned)(32 * G.co_tot * 2), xrow32 = (unsigned)(32 * G.ca_tot * 2);
+  const char* const zsrc = (const char*)g_wzero + (lane & 15) * 16;
+  const size_t dstep = (size_t)64 * G.co_tot * 2, xstep = (size_t)64 * G.ca_tot * 2;
+  const char* const dy1b = (const char*)p.dy1 + (size_t)mbeg * G.co_tot * 2;
+  const char* const x1b = (const char*)p.x1 + (size_t)mbeg * G.ca_tot * 2;
+  const char* const dy2b = (const char*)(p.dy2 ? p.dy2 : p.dy1) + (size_t)mbeg * G.co_tot * 2;
+  const char* const x2b = (const char*)(p.x2 ? p.x2 : p.x1) + (size_t)mbeg * G.ca_tot * 2;
+  typedef const void __attribute__((address_space(1)))* gptr_t;
+  typedef void __attribute__((address_space(3)))* lptr_t;
+  // half-tile hh = 4*kt + {0: D0, 1: X0, 2: X1, 3: D1} -> ring slot hh % NS (the caller passes it)
+  auto issue = [&](int hh, int slot) __attribute__((always_inline)) {
+    const int kt = hh >> 2, jj = hh & 3;
+    const bool second = kt >= nk1;
+    const int ktl = second ? kt - nk1 : kt;
+    const bool isd = jj == 0 || jj == 3;
+    const int h = jj >= 2 ? 1 : 0;
+    const char* base = isd ? (second ? dy2b : dy1b) + ktl * dstep : (second ? x2b : x1b) + ktl * xstep;
+    const int rem = rows - ktl * 64;
+    if constexpr (MDD_WGP_ABL & 2) return;
+    char* dst = smem + slot * 16384 + wave * 1024;
+    const bool colok = isd ? (dch0 + 128 * h) < G.nc : (xkk0 + 128 * h) < ktot;
+    const unsigned vo = (isd ? dv0 : xv0) + 256u * h;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const char* src = (colok && lrow0 + 32 * j < rem) ? base + vo + (j ? (isd ? drow32 : xrow32) : 0u) : zsrc;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + j * 8192), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment geometry (as the one-stage kernel): 16-lane group gq, lane li = 4q + pp reads the 4-row block
+  // rho(gq, e) of a 32-pixel K-step, rows 8x..8x+3 / 8x+4..8x+7 per half-wave: conflict-free with the swizzle
+  const int gq = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+  // byte offsets inside a half-tile slot of block 0 (e = 0, 1); block i is XOR 32*i (the swizzle and the block index
+  // occupy the same bits of the 8-byte unit index), the second 32-pixel step is + 8192
+  unsigned rdD0[2], rdX0[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int row = 4 * (2 * (2 * e + (gq >> 1)) + (gq & 1)) + q;
+    const int sw = (row & 7) << 2;
+    rdD0[e] = (unsigned)(row * 256 + ((((wc * 64 + 4 * pp) >> 2) ^ sw) << 3));
+    rdX0[e] = (unsigned)(row * 256 + ((((wk * 32 + 4 * pp) >> 2) ^ sw) << 3));
+  }
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+  // bias gradient (column sums of dy1) from the D half-tiles in LDS, by the blocks of k'-tile 0: thread t adds the
+  // chunks (row t>>4 + 32u, slot t&15) -- one fixed 8-channel chunk of the half-tile per thread
+  const bool do_bias = p.dbias != nullptr && kpt == 0;
+  float bsum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+  const int brow = (tid & 255) >> 4, bslot = tid & 15;     // waves 0-3 sum D0, waves 4-7 D1: rows brow + 16u
+  auto bias_add = [&](unsigned slot) __attribute__((always_inline)) {     // asm reads, as the fragments: no vmcnt(0)
+    const unsigned a = slot + (unsigned)(brow * 256 + bslot * 16);
+    u32x4 c[4];
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:4096\n\tds_read_b128 %2, %4 offset:8192\n\t"
+                 "ds_read_b128 %3, %4 offset:12288\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]) : "v"(a));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float f[8];
+      Chunk<bf16>::unpack(__builtin_bit_cast(uint4, c[u]), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bsum[e] += f[e];
+    }
+  };
+
+  // The transposing reads are inline asm: hipcc orders a ds_read_tr builtin behind EVERY outstanding LDS-DMA
+  // (s_waitcnt vmcnt(0) in front of it), which would drain the ring each phase.  Their completion is counted by the
+  // wait statements below, which name every destination register so that no consumer is scheduled above them.
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+  s16x4 af[2][2][4], b0[2][2][2], b1[2][2][2];
+  auto tr0 = [](unsigned a) __attribute__((always_inline)) {
+    s16x4 v;
+    if constexpr (MDD_WGP_ABL & 4) asm volatile("" : "=v"(v) : "v"(a)); else
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(a));
+    return v;
+  };
+  auto tr1 = [](unsigned a) __attribute__((always_inline)) {
+    s16x4 v;
+    if constexpr (MDD_WGP_ABL & 4) asm volatile("" : "=v"(v) : "v"(a)); else
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(v) : "v"(a));
+    return v;
+  };
+  auto read_d = [&](unsigned slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned a = (slot + rdD0[e]) ^ (unsigned)(32 * i);
+        af[0][e][i] = tr0(a);
+        af[1][e][i] = tr1(a);
+      }
+  };
+  auto read_x = [&](unsigned slot, s16x4 (&b)[2][2][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const unsigned a = (slot + rdX0[e]) ^ (unsigned)(32 * j);
+        b[0][e][j] = tr0(a);
+        b[1][e][j] = tr1(a);
+      }
+  };
+#define MDD_B8(b) "+v"(b[0][0][0]), "+v"(b[0][0][1]), "+v"(b[0][1][0]), "+v"(b[0][1][1]), "+v"(b[1][0][0]), "+v"(b[1][0][1]), \
+                  "+v"(b[1][1][0]), "+v"(b[1][1][1])
+#define MDD_A16 "+v"(af[0][0][0]), "+v"(af[0][0][1]), "+v"(af[0][0][2]), "+v"(af[0][0][3]), "+v"(af[0][1][0]), "+v"(af[0][1][1]), \
+                "+v"(af[0][1][2]), "+v"(af[0][1][3]), "+v"(af[1][0][0]), "+v"(af[1][0][1]), "+v"(af[1][0][2]), "+v"(af[1][0][3]),  \
+                "+v"(af[1][1][0]), "+v"(af[1][1][1]), "+v"(af[1][1][2]), "+v"(af[1][1][3])
+  auto quad = [&](const s16x4 (&b)[2][2][2], int ia, int jb) __attribute__((always_inline)) {
+    if constexpr (MDD_WGP_ABL & 1) return;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const s16x8 a8 = __builtin_shufflevector(af[ks][0][i], af[ks][1][i], 0, 1, 2, 3, 4, 5, 6, 7);
+          const s16x8 b8 = __builtin_shufflevector(b[ks][0][j], b[ks][1][j], 0, 1, 2, 3, 4, 5, 6, 7);
+          acc[ia + i][jb + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b8), __builtin_bit_cast(bf16x8, a8),
+                                                                        acc[ia + i][jb + j], 0, 0, 0);
+        }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+#pragma unroll
+  for (int hh = 0; hh < D; ++hh)
+    if (hh < H) issue(hh, hh);
+  if (H >= D + 2) wait_vm<2 * (D - 2)>(); else wait_vm<0>();    // D0, X0 of K-tile 0 have landed (this wave's share)
+  int sb = 0;                                     // ring slot of this K-tile's first half-tile = (4 kt) % NS
+  auto slot_of = [](int s) __attribute__((always_inline)) { return s >= 2 * NS ? s - 2 * NS : (s >= NS ? s - NS : s); };
+  raw_barrier();
+  if (wc == 1) raw_barrier();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int g0 = 4 * kt;
+    const int o0 = slot_of(sb) * 16384, o1 = slot_of(sb + 1) * 16384, o2 = slot_of(sb + 2) * 16384, o3 = slot_of(sb + 3) * 16384;
+    const bool bias_now = do_bias && kt < nk1;
+    // ---- phase 0: D0, X0 ; quadrant (0, 0)
+    if (bias_now && wc == 0) bias_add(lds0 + o0);
+    read_x(lds0 + o1, b0);
+    read_d(lds0 + o0);
+    if (g0 + D < H) { issue(g0 + D, slot_of(sb + D)); wait_vm<2 * (D - 2)>(); } else wait_vm<0>();
+    raw_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" : MDD_B8(b0), MDD_A16);
+    quad(b0, 0, 0);
+    raw_barrier();
+    // ---- phase 1: X1 ; quadrant (0, 1)
+    read_x(lds0 + o2, b1);
+    if (g0 + D + 1 < H) { issue(g0 + D + 1, slot_of(sb + D + 1)); wait_vm<2 * (D - 2)>(); } else wait_vm<0>();
+    raw_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" : MDD_B8(b1));
+    quad(b1, 0, 2);
+    raw_barrier();
+    // ---- phase 2: D1 ; quadrant (1, 1)
+    if (bias_now && wc == 1) bias_add(lds0 + o3);
+    read_d(lds0 + o3);
+    if (g0 + D + 2 < H) { issue(g0 + D + 2, slot_of(sb + D + 2)); wait_vm<2 * (D - 1)>(); } else wait_vm<0>();
+    raw_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" : MDD_A16);
+    quad(b1, 4, 2);
+    raw_barrier();
+    // ---- phase 3: nothing new ; quadrant (1, 0)
+    if (g0 + D + 3 < H) { issue(g0 + D + 3, slot_of(sb + D + 3)); wait_vm<2 * (D - 2)>(); } else wait_vm<0>();
+    raw_barrier();
+    quad(b0, 4, 0);
+    raw_barrier();
+    sb = slot_of(sb + 4);
+  }
+#undef MDD_B8
+#undef MDD_A16
+  if (wc == 0) raw_barrier();
+  __syncthreads();
+
+  // ---- write-out: rows = k' (4 consecutive per lane), columns = co, as the one-stage kernel
+  float* dst = p.slab ? p.slab + (size_t)bsplit * p.slab_stride : p.dW;
+  const bool plain = p.slab != nullptr;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (MDD_WGP_ABL & 8) { asm volatile("" :: "v"(acc[i][j])); continue; }
+      const int co = co0 + (i >> 2) * 128 + wc * 64 + 16 * (i & 3) + li, kcol = kp0 + (j >> 1) * 128 + wk * 32 + 16 * (j & 1) + 4 * gq;
+      if (co >= G.nc || kcol >= ktot) continue;
+      float* a = dst + (size_t)co * ktot + kcol;
+      if (plain) {
+        *(float4*)a = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      } else {
+        atomicAdd(a, acc[i][j][0]); atomicAdd(a + 1, acc[i][j][1]); atomicAdd(a + 2, acc[i][j][2]); atomicAdd(a + 3, acc[i][j][3]);
+      }
+    }
+  if (do_bias) {
+    float* sh = (float*)smem;     // [2 halves][16 rows][128 columns]
+    const int cidx = bslot ^ ((brow & 7) << 1);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sh[(wc * 16 + brow) * 128 + cidx * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < 256) {
+      const int h = tid >> 7, col = tid & 127;
+      float s = 0.f;
+      for (int r = 0; r < 16; ++r) s += sh[(h * 16 + r) * 128 + col];
+      const int ch = co0 + h * 128 + col;
+      if (ch < G.nc) atomicAdd(p.dbias + ch, s);
+    }
+  }
+}
+
+// split policy and launch of k_wgrad_pipe; false = shape not taken (the caller falls through to the one-stage kernel)
+bool launch_pipe(WArgs a, float* slab, int64_t slab_floats, hipEvent_t ev_mid, hipStream_t st) {
+  const ConvGeom& g = a.g;
+  const bool pw = g.k == 1 && g.stride == 1 && g.pad == 0 && g.groups == 1;
+  if (!pw || g.nc < MDD_WG_PIPE_MIN || g.kc < MDD_WG_PIPE_MIN || (g.kc & 7) || (g.nc & 7) || (g.co_tot & 7) || (g.ca_tot & 7) ||
+      a.M < 2048)
+    return false;
+  const int ktot = g.kc;
+  a.cotiles = (g.nc + 255) / 256;
+  a.kptiles = (ktot + 255) / 256;
+  const int tiles = a.cotiles * a.kptiles;
+  const int nsrc = a.dy2 ? 2 : 1;
+  const int64_t out_floats = (int64_t)g.nc * ktot;
+  const double out_mb = (double)out_floats * 4.0 / 1e6;
+  const bool two_phase = slab != nullptr && slab_floats >= out_floats && out_floats % 4 == 0 && ((uintptr_t)a.dW & 15) == 0;
+  const double comb_us_per_mb = two_phase ? 0.6 : 1.0 / 1.3;
+  int maxsplits = a.M / 256;     // at least four K-tiles per block
+  if (two_phase && maxsplits > slab_floats / out_floats) maxsplits = (int)(slab_floats / out_floats);
+  if (maxsplits < 1) maxsplits = 1;
+  int splits = 1;
+  double best = 1e30;
+  for (int sp = 1; sp <= maxsplits; ++sp) {
+    const int chunk = ((a.M + sp - 1) / sp + 63) / 64 * 64;
+    const double steps = (double)nsrc * chunk / 64;
+    const double waves = (double)(((int64_t)tiles * sp + 255) / 256);      // one block per CU
+    const double t = waves * (steps * 0.9 + 8.0) + out_mb * sp * comb_us_per_mb;
+    if (t < best) { best = t; splits = sp; }
+  }
+  int mchunk = ((a.M + splits - 1) / splits + 63) / 64 * 64;
+  splits = (a.M + mchunk - 1) / mchunk;
+  if (a.M - (splits - 1) * mchunk < 1) return false;
+  a.mchunk = mchunk;
+  a.dbg = 0;
+  a.slab = two_phase ? slab : nullptr;
+  a.slab_stride = out_floats;
+  static std::atomic<uint64_t> attr_devs{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
+    if (hipFuncSetAttribute((const void*)k_wgrad_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, WGP_NS * 16384) != hipSuccess) return false;
+    attr_devs.fetch_or(bit, std::memory_order_release);
+  }
+  k_wgrad_pipe<<<dim3(tiles, splits), 512, WGP_NS * 16384, st>>>(a);
+  if (ev_mid) (void)hipEventRecord(ev_mid, st);
+  if (two_phase) {
+    const int64_t n4 = out_floats / 4;
+    k_wgrad_reduce<<<(unsigned)((n4 + 15) / 16), 256, 0, st>>>(a.dW, slab, n4, out_floats / 4, splits);
+  }
+  return true;
+}
+
 template <class AT, int BCO, int BKP, int BKM>
 void launch_cfg(WArgs a, float* slab, int64_t slab_floats, hipEvent_t ev_mid, hipStream_t st) {
   const bool pw = a.g.k == 1 && a.g.stride == 1 && a.g.pad == 0;
@@ -567,6 +901,7 @@ void launch_conv_wgrad(const ConvGeom& g, const AT* dy1, const AT* x1, const AT*
   a.M = g.nimg * g.ho * g.wo;
   a.cotiles = a.kptiles = a.mchunk = 0;
   if constexpr (sizeof(AT) == 2) {
+    if (launch_pipe(a, slab, slab_floats, ev_mid, st)) return;
     if (g.nc > 64) launch_cfg<AT, 128, 128, MDD_WG_BKM>(a, slab, slab_floats, ev_mid, st);
     else launch_cfg<AT, 64, 128, MDD_WG_BKM>(a, slab, slab_floats, ev_mid, st);
   } else {

@@ -1886,6 +1886,26 @@ int mdd_op_conv2d_wgrad(int dtype, int nimg, int hin, int win, int cin, int cout
   return 0;
 }
 
+int mdd_op_conv2d_wgrad2(int dtype, int nimg, int hin, int win, int cin, int cout, int k, int stride,
+                         int pad, int groups, const void* dy1, const void* x1, const void* dy2, const void* x2,
+                         float* dw, float* db, float* ws, long long ws_floats, void* stream) {
+  CHECK_ARG(dy1 && x1 && dw, "null pointer");
+  CHECK_ARG((dy2 == nullptr) == (x2 == nullptr), "the second pair is given whole or not at all");
+  CHECK_ARG(dtype >= 0 && dtype <= 3, "dtype");
+  CHECK_ARG(ws_floats >= 0 && (ws != nullptr || ws_floats == 0), "workspace");
+  ConvGeom g = op_geom(0, nimg, hin, win, cin, cout, k, stride, pad, groups);
+  if (dtype == MDD_DTYPE_BF16X2) g.prec = 1;
+  if (dtype == MDD_DTYPE_F32_BF16OPS) g.prec = 2;
+  if (dtype != MDD_DTYPE_BF16)
+    launch_conv_wgrad<float>(g, (const float*)dy1, (const float*)x1, (const float*)dy2, (const float*)x2, dw, db, ws,
+                             (int64_t)ws_floats, nullptr, (hipStream_t)stream);
+  else
+    launch_conv_wgrad<bf16>(g, (const bf16*)dy1, (const bf16*)x1, (const bf16*)dy2, (const bf16*)x2, dw, db, ws,
+                            (int64_t)ws_floats, nullptr, (hipStream_t)stream);
+  POST_LAUNCH("op_conv2d_wgrad2");
+  return 0;
+}
+
 int mdd_retrieval_ranks(const float* img_feat, const float* txt_feat, const int* img2txt_off,
                         const int* img2txt_idx, const int* txt2img, int n_img, int n_txt, int dim,
                         float scale, float* scores_ws, float* norm_ws, int* rank_i2t, int* rank_t2i,

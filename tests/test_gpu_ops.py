@@ -103,6 +103,37 @@ def test_conv_ops(case, dtype, report):
     assert e_f < tol and e_d < tol and e_w < tol and e_b < tol
 
 
+@pytest.mark.parametrize("pairs", [1, 2])
+@pytest.mark.parametrize("workspace", [False, True])
+@pytest.mark.parametrize("shape", [(2352, 768, 512), (2352, 520, 776), (4500, 1024, 768), (2100, 512, 1032)])
+def test_wide_pointwise_wgrad(shape, workspace, pairs, report):
+    """Weight gradient of wide pointwise layers in bf16 (the ViT linears: csrc/conv_wgrad.hip k_wgrad_pipe, 256 x 256
+    tiles, LDS-DMA ring): one / two operand pairs, split-M workspace or atomics, channel counts that are not a
+    multiple of the tile, a pixel count that is not a multiple of the K-tile.  Reference: fp32 matmul of the same
+    bf16 operands (only the summation order differs: 1e-5)."""
+    from multimodal_dataset_distillation_amd import _lib
+    lib = _lib.load()
+    M, cin, cout = shape
+    dev = "cuda"
+    torch.manual_seed(M + cin + pairs)
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x = [torch.randn(M, cin, device=dev).bfloat16() for _ in range(pairs)]
+    dy = [torch.randn(M, cout, device=dev).bfloat16() for _ in range(pairs)]
+    ws = torch.empty(12 * cin * cout, device=dev) if workspace else None
+    dw = torch.full((cout, cin), float("nan"), device=dev) if workspace else torch.zeros(cout, cin, device=dev)
+    db = torch.zeros(cout, device=dev)
+    _lib.check(lib.mdd_op_conv2d_wgrad2(1, M, 1, 1, cin, cout, 1, 1, 0, 1, P(dy[0]), P(x[0]),
+                                        P(dy[1]) if pairs == 2 else None, P(x[1]) if pairs == 2 else None,
+                                        P(dw), P(db), P(ws), ws.numel() if workspace else 0, st))
+    torch.cuda.synchronize()
+    ref = sum(d.float().t() @ a.float() for d, a in zip(dy, x))
+    rb = dy[0].float().sum(0)
+    e_w, e_b = rel_err(dw.cpu(), ref.cpu()), rel_err(db.cpu(), rb.cpu())
+    report(f"wide pointwise wgrad bf16 {shape} pairs {pairs} workspace {workspace}: dW {e_w:.2e} bias {e_b:.2e}")
+    assert e_w < 1e-5 and e_b < 1e-5
+
+
 def test_flat_ops(report):
     from multimodal_dataset_distillation_amd import _lib
     lib = _lib.load()
