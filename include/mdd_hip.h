@@ -65,10 +65,14 @@ typedef struct mdd_config {
 
 const char* mdd_last_error(void);
 /* ABI version of this header: 2 = round 2 (mdd_config.keep_steps, MDD_DTYPE_BF16X2 / _F32_BF16OPS,
- * profile kind 4); 3 = + mdd_comm_* / mdd_allreduce_syn_grads; 4 = + the ViT building-block ops; 5 = + mdd_engine_set_pass_precision.  A binding built against another version
+ * profile kind 4); 3 = + mdd_comm_* / mdd_allreduce_syn_grads; 4 = + the ViT building-block ops; 5 = + mdd_engine_set_pass_precision; 6 = + mdd_op_conv2d_wgrad2, mdd_set_pipe_kernels.  A binding built against another version
  * must refuse to load. */
 #define MDD_ABI_VERSION 6
 int mdd_version(void);
+/* The wide bf16 pointwise contractions (>= 512 channels in and out, >= 8192 rows: the ViT linears) run on 256 x 256-tile
+ * pipelined kernels; 0 routes them to the general kernels instead (process-wide; returns the previous setting).  For the
+ * parity tests, which compare an iteration both ways, and for A/B timing. */
+int mdd_set_pipe_kernels(int enable);
 
 /* ---- engine lifetime and memory (the caller owns device memory: PyTorch caching allocator) */
 int mdd_engine_create(const mdd_config* cfg, mdd_engine** out);

@@ -66,6 +66,7 @@ SIGNATURES = {
     "mdd_unrolled_match": (_I, [_P, C.POINTER(MddIterArgs), _P]),
     "mdd_op_conv2d": (_I, [_I] * 11 + [_P, _P, _P, _P, _P]),
     "mdd_op_conv2d_wgrad": (_I, [_I] * 10 + [_P, _P, _P, _P, _P]),
+    "mdd_set_pipe_kernels": (_I, [_I]),
     "mdd_op_conv2d_wgrad2": (_I, [_I] * 10 + [_P] * 7 + [C.c_longlong, _P]),
     "mdd_op_contrastive_workspace_floats": (_L, [_I, _I]),
     "mdd_op_contrastive": (_I, [_I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P]),

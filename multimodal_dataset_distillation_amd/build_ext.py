@@ -15,7 +15,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libmdd_hip.so")
 SOURCES = ["flat_ops.hip", "ws.hip", "elementwise.hip", "linear.hip", "head.hip", "conv_gemm.hip",
            "conv_wgrad.hip", "retrieval.hip", "collective.hip", "vit.hip", "attn.hip", "engine.hip"]
-HEADERS = ["common.h", "kernels.h", "engine.h", os.path.join("..", "..", "include", "mdd_hip.h")]
+HEADERS = ["common.h", "kernels.h", "engine.h", "conv_gemm_epilogue.inc", os.path.join("..", "..", "include", "mdd_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result",
          "-I", os.path.join(HERE, "..", "include")]
 

@@ -568,190 +568,195 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
     __syncthreads();
   }
 
-  // ---- epilogue.  The accumulators (C/D map of the 32x32 MFMA: col = lane&31,
-  // row = (r&3) + 8*(r>>2) + 4*(lane>>5)) are transposed through this wave's LDS region so that
-  // every lane owns one 16-byte chunk of consecutive channels: all epilogue reads (bias, stashed
-  // c / c_t / a-bar, residual adds) and all stores are 16-byte vector accesses on full NHWC rows.
-  constexpr int WROWS = TM * 32, WCOLS = TN * 32, PITCH = WCOLS + 4;
-  constexpr int LPR = WCOLS / CE;      // lanes per output row
-  constexpr int RPP = 64 / LPR;        // rows per pass
-  if (MDD_DBG_BITS(p) & 4) return;   // dbg bit2: no epilogue at all (timing only)
-  float* stage = (float*)smem + wave * (32 * PITCH);   // one 32-row MFMA block at a time
-  const ConvEpi& E = p.ep;
-  AT* out_raw = (AT*)E.out_raw;
-  AT* out_act = (AT*)E.out_act;
-  const AT* Cst = (const AT*)E.c;
-  const AT* Ct = (const AT*)E.c_t;
-  const AT* Ab = (const AT*)E.abar;
-  const AT* add1 = (const AT*)E.add1;
-  const AT* add2 = (const AT*)E.add2;
-  const int lrow = lane / LPR, lcol = (lane % LPR) * CE;
-  const int n = n0 + wn * WCOLS + lcol;
-  const bool ncol_ok = n < G.nc;
-  const int ch = grp * G.nc + n;
-  float bias[CE];
-#pragma unroll
-  for (int e = 0; e < CE; ++e) bias[e] = 0.f;
-  const float* bp = E.mode == EPI_FWD ? E.bias : (E.mode == EPI_FWD_T ? E.bias_t : nullptr);
-  if (bp && ncol_ok) {
-#pragma unroll
-    for (int e = 0; e < CE; e += 4) {
-      float4 b4 = *(const float4*)(bp + ch + e);
-      bias[e] = b4.x; bias[e + 1] = b4.y; bias[e + 2] = b4.z; bias[e + 3] = b4.w;
-    }
-  }
-  // The epilogue body is instantiated once per ConvEpi mode and picked by ONE uniform switch, so each
-  // instance only contains the operand loads and the math of its mode (a generic body paid 16-byte
-  // selects for every absent operand, a mode switch per row pass and 64-bit row indices: +30..70 % on
-  // short-K launches against tools/micro/gemm_core.hip).  Within an instance the output pointers may
-  // alias the stashed operands as far as the compiler can tell, so it will not hoist the loads of pass
-  // p+1 above the stores of pass p by itself: the loop is software-pipelined by hand -- the global loads of
-  // U row passes are issued first, then the U passes are computed and stored.
-  constexpr int NP = 32 / RPP;
-  constexpr int U = NP < MDD_EPI_UNROLL ? NP : MDD_EPI_UNROLL;
-  const bool ldop = !(MDD_DBG_BITS(p) & 8);                          // dbg bit3: no epilogue operand loads (timing only)
-  const bool nomath = (MDD_DBG_BITS(p) & 16) != 0;                   // dbg bit4: no activation math (timing only)
-  const bool nostore = (MDD_DBG_BITS(p) & 2) != 0;                   // dbg bit1: no stores (timing only)
-  const float beta = E.beta;
-  auto run = [&](auto EMc, auto FTc, auto IBc) __attribute__((always_inline)) {
-    constexpr int EM = decltype(EMc)::value;
-    constexpr bool FULLT = decltype(FTc)::value;   // every row of the block tile is a real output row
-    // per-image bias (data-gradient modes): the accumulator row of pixel m gets ib[m / hw][channel] * ib_mul
-    // added -- the pooled squeeze-excite path's gradient, broadcast over the pixels of its image
-    constexpr bool IB = IBK && decltype(IBc)::value && (EM == EPI_BWD || EM == EPI_BWD_T);
-    const float* ibp = EM == EPI_BWD_T ? E.ib_t : E.ib;
-    const float ib_inv = IB ? 1.f / (float)E.ib_hw : 0.f;
-    constexpr bool HAS_C = EM == EPI_FWD_T || EM == EPI_BWD || EM == EPI_BWD_T;   // stashed pre-activation
-    constexpr bool HAS_T = EM == EPI_BWD_T;                                       // its tangent + a-bar
-    constexpr bool HAS_ACT = EM != EPI_BWD_LIN;
-    const bool use_a1 = add1 != nullptr && ldop && EM != EPI_FWD;
-    const bool use_a2 = add2 != nullptr && ldop && HAS_ACT && out_act != nullptr;
-    const bool do_act = HAS_ACT && out_act != nullptr;
-    // four 16-byte operands per pass (tangent backward) or the parity-class row remap (MODE 2): fewer passes in flight
-    constexpr int UU = ((EM == EPI_BWD_T || MODE == 2) && U > 2) ? U / 2 : U;
-#pragma unroll
-    for (int hi = 0; hi < TM; ++hi) {
-      // this wave's 32-row block hi of the accumulators -> its private LDS stage (aliases the K-loop
-      // buffers: the loop's final barrier has retired every read of them)
-      if (hi) __syncthreads();
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + j * 32 + l31] = acc[hi][j][r];
-      __syncthreads();
-      if (!ncol_ok) continue;
-#pragma unroll 1
-      for (int ps0 = 0; ps0 < NP; ps0 += UU) {
-        int idx[UU];
-        bool ok[UU];
-        uint4 q_a1[UU], q_c[UU], q_ct[UU], q_ab[UU], q_a2[UU];
-        float4 q_ib[IB ? UU : 1][IB ? CE / 4 : 1];
-#pragma unroll
-        for (int u = 0; u < UU; ++u) {
-          const int row = (ps0 + u) * RPP + lrow;
-          int m = m0 + wm * WROWS + hi * 32 + row;
-          ok[u] = FULLT || m < e_M;
-          if constexpr (IB) {
-            if (ok[u]) {
-              int img = (int)((float)m * ib_inv);            // estimate, then exact by one correction step
-              const int rem = m - img * E.ib_hw;
-              img += rem >= E.ib_hw ? 1 : (rem < 0 ? -1 : 0);
-              const float* q = ibp + (size_t)img * G.co_tot + ch;
-#pragma unroll
-              for (int e = 0; e < CE / 4; ++e) q_ib[u][e] = *(const float4*)(q + 4 * e);
-            }
-          }
-          if constexpr (MODE == 2) {   // class-local pixel -> full-resolution output pixel
-            int oxc = m % e_wo, t = m / e_wo;
-            int oyc = t % e_ho, ni = t / e_ho;
-            m = (ni * G.ho + 2 * oyc + py) * G.wo + 2 * oxc + px;
-          }
-          idx[u] = m * G.co_tot + ch;          // < 2^31 elements for every tensor of the path
-          if (ok[u]) {
-            if (use_a1) q_a1[u] = *(const uint4*)(add1 + idx[u]);
-            if constexpr (HAS_C) { if (do_act && ldop) q_c[u] = *(const uint4*)(Cst + idx[u]); }
-            if constexpr (HAS_T) {
-              if (do_act && ldop) { q_ct[u] = *(const uint4*)(Ct + idx[u]); q_ab[u] = *(const uint4*)(Ab + idx[u]); }
-            }
-            if (use_a2) q_a2[u] = *(const uint4*)(add2 + idx[u]);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < UU; ++u) {
-          if (!ok[u]) continue;
-          const int row = (ps0 + u) * RPP + lrow;
-          float v[CE], t0[CE], t1[CE], t2[CE], o[CE];
-#pragma unroll
-          for (int e = 0; e < CE; e += 4) {
-            float4 s4 = *(const float4*)(stage + row * PITCH + lcol + e);
-            v[e] = s4.x + bias[e]; v[e + 1] = s4.y + bias[e + 1];
-            v[e + 2] = s4.z + bias[e + 2]; v[e + 3] = s4.w + bias[e + 3];
-          }
-          if (use_a1) {
-            Chunk<AT>::unpack(q_a1[u], t0);
-#pragma unroll
-            for (int e = 0; e < CE; ++e) v[e] += t0[e];
-          }
-          if constexpr (IB) {
-#pragma unroll
-            for (int e = 0; e < CE / 4; ++e) {
-              v[4 * e] += q_ib[u][e].x * E.ib_mul; v[4 * e + 1] += q_ib[u][e].y * E.ib_mul;
-              v[4 * e + 2] += q_ib[u][e].z * E.ib_mul; v[4 * e + 3] += q_ib[u][e].w * E.ib_mul;
-            }
-          }
-          if (out_raw && !nostore) *(uint4*)(out_raw + idx[u]) = Chunk<AT>::pack(v);
-          if constexpr (HAS_ACT) {
-            if (!do_act) continue;
-            if (nomath || (HAS_C && !ldop)) {
-#pragma unroll
-              for (int e = 0; e < CE; ++e) o[e] = v[e];
-            } else if constexpr (EM == EPI_FWD) {
-#pragma unroll
-              for (int e = 0; e < CE; ++e) o[e] = beta * actf<ACT>(v[e]);
-            } else if constexpr (EM == EPI_BWD_T) {
-              Chunk<AT>::unpack(q_c[u], t0); Chunk<AT>::unpack(q_ct[u], t1); Chunk<AT>::unpack(q_ab[u], t2);
-#pragma unroll
-              for (int e = 0; e < CE; ++e) o[e] = beta * (dactf<ACT>(Dual(t0[e], t1[e])) * Dual(t2[e], v[e])).t;
-            } else {   // EPI_FWD_T, EPI_BWD
-              Chunk<AT>::unpack(q_c[u], t0);
-#pragma unroll
-              for (int e = 0; e < CE; ++e) o[e] = beta * dactf<ACT>(t0[e]) * v[e];
-            }
-            if (use_a2) {
-              Chunk<AT>::unpack(q_a2[u], t0);
-#pragma unroll
-              for (int e = 0; e < CE; ++e) o[e] += t0[e];
-            }
-            if (!nostore) *(uint4*)(out_act + idx[u]) = Chunk<AT>::pack(o);
-          }
-        }
-      }
-    }
-  };
-  const bool full_tile = MODE != 2 && m0 + BM <= e_M;
-#define MDD_RUN(EMV, IBV)                                                                              \
-  do {                                                                                                 \
-    if (MODE != 2 && full_tile) run(std::integral_constant<int, EMV>{}, std::true_type{}, IBV{});     \
-    else run(std::integral_constant<int, EMV>{}, std::false_type{}, IBV{});                           \
-  } while (0)
-  // the per-image bias exists only on pointwise data gradients (conv3 of a residual block): those launches
-  // use the IBK instance of the kernel, which contains nothing but the two epilogues that take it
-  if constexpr (IBK) {
-    if (E.mode == EPI_BWD) MDD_RUN(EPI_BWD, std::true_type);
-    else MDD_RUN(EPI_BWD_T, std::true_type);
-  } else {
-    switch (E.mode) {
-      case EPI_FWD: MDD_RUN(EPI_FWD, std::false_type); break;
-      case EPI_FWD_T: MDD_RUN(EPI_FWD_T, std::false_type); break;
-      case EPI_BWD: MDD_RUN(EPI_BWD, std::false_type); break;
-      case EPI_BWD_T: MDD_RUN(EPI_BWD_T, std::false_type); break;
-      default: MDD_RUN(EPI_BWD_LIN, std::false_type); break;
-    }
-  }
-#undef MDD_RUN
+#include "conv_gemm_epilogue.inc"
 }
 
+
+// ======================================================================================================
+// Wide pointwise layers in bf16 (the ViT linears: 19,700 token rows, K and N in 768..3072): a 256 x 256 output tile
+// per 512-thread block, one block per CU, the schedule of tools/micro/gemm_pipe.hip (and of k_wgrad_pipe):
+//   * 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 = acc[4][2] of v_mfma_f32_32x32x16_bf16
+//   * a K-tile (64 deep) = four HALF-TILES of 128 rows x 128 B (16 KB): A0, B0, B1, A1 -- A_h holds rows [64h, 64h+64) of
+//     both wave rows, B_h columns [32h, 32h+32) of all four wave columns, so every wave needs them in the same order --
+//     in an 8-slot LDS ring filled by global_load_lds_dwordx4 six phases ahead (swizzle on the source address)
+//   * a K-tile = four PHASES: {ds_read_b128 this phase's fragments, issue one half-tile, counted vmcnt} barrier
+//     {8 MFMAs: one 64 x 32 quadrant x K 64} barrier; wave row 1 runs ONE barrier behind wave row 0, so of the two
+//     waves of a SIMD one issues MFMAs while the other reads LDS.  Hazard rules: see k_wgrad_pipe (conv_wgrad.hip).
+// Rows past M and columns past nc are clamped (computed, never stored).  The epilogue is the common one.
+#ifndef MDD_PIPE_MIN
+#define MDD_PIPE_MIN 512     // narrowest layer (K and output channels) taken by k_gemm_pipe
+#endif
+template <int N_> DEVI void wait_vm() {
+  __builtin_amdgcn_s_waitcnt((N_ & 0xF) | ((N_ >> 4) << 14) | (0x7 << 4) | (0xF << 8));
+}
+DEVI void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+template <int ACT>
+__global__ __launch_bounds__(512, 1) void k_gemm_pipe(const KArgs p) {
+  typedef bf16 AT;
+  constexpr int TM = 4, TN = 2, MODE = 0, CE = 8, BM = 256;
+  constexpr bool IBK = false;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const ConvGeom& G = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
+  int bid;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  }
+  const int nt = bid % p.ntiles, mt = bid / p.ntiles, grp = 0;
+  const int e_M = p.M, e_ho = G.ho, e_wo = G.wo, py = 0, px = 0;
+  const int m0 = mt * 256, n0 = nt * 256;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int K = G.kc;
+  const int nk1 = K >> 6;
+  const int nk = p.A2 ? 2 * nk1 : nk1, H = 4 * nk;
+  // loader: per half-tile two 1-KB wave instructions; instruction j covers LDS rows j*64 + wave*8 + (lane>>3), this
+  // lane's 16-byte slot lane&7 receives global chunk slot ^ swizzle(row)
+  unsigned aoff[2][2], boff[2][2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = j * 64 + wave * 8 + (lane >> 3);
+      const int ch = (lane & 7) ^ ((r >> 1) & 7);
+      int m = m0 + (r >> 6) * 128 + hh * 64 + (r & 63); if (m >= e_M) m = e_M - 1;
+      int n = n0 + (r >> 5) * 64 + hh * 32 + (r & 31); if (n >= G.nc) n = G.nc - 1;
+      aoff[hh][j] = (unsigned)((m * G.ca_tot + ch * 8) * 2);
+      boff[hh][j] = (unsigned)((n * K + ch * 8) * 2);
+    }
+  int rdA[4], rdB[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int ra_ = wm * 64 + l31, rb_ = wn * 32 + l31;
+    rdA[q] = ra_ * 128 + (((2 * q + lh) ^ ((ra_ >> 1) & 7)) << 4);
+    rdB[q] = rb_ * 128 + (((2 * q + lh) ^ ((rb_ >> 1) & 7)) << 4);
+  }
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  typedef const void __attribute__((address_space(1)))* gptr_t;
+  typedef void __attribute__((address_space(3)))* lptr_t;
+  // half-tile h = 4*kt + {0: A0, 1: B0, 2: B1, 3: A1} -> ring slot h & 7
+  auto issue = [&](int h) __attribute__((always_inline)) {
+    const int kt = h >> 2, jj = h & 3;
+    const bool second = kt >= nk1;
+    const int ktl = second ? kt - nk1 : kt;
+    const bool isa = jj == 0 || jj == 3;
+    const int hh = jj >= 2 ? 1 : 0;
+    const char* src = (const char*)(isa ? (second ? p.A2 : p.A1) : (second ? p.B2 : p.B1)) + (size_t)ktl * 128;
+    char* dst = smem + (h & 7) * 16384 + wave * 1024;
+    const unsigned o0 = isa ? aoff[hh][0] : boff[hh][0], o1 = isa ? aoff[hh][1] : boff[hh][1];
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + o0), (lptr_t)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + o1), (lptr_t)(dst + 8192), 16, 0, 0);
+  };
+  auto mma = [](const u32x4& a, const u32x4& b, f32x16& c) __attribute__((always_inline)) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  };
+#pragma unroll
+  for (int h = 0; h < 6; ++h) issue(h);       // the launcher guarantees K >= 128: at least eight half-tiles exist
+  wait_vm<8>();                                // A0, B0 of K-tile 0 have landed (this wave's share)
+  raw_barrier();
+  if (wm == 1) raw_barrier();
+  u32x4 af[2][4], b0[4], b1[4];
+  for (int kt = 0; kt < nk; ++kt) {
+    const int g0 = 4 * kt;
+    const char* sA0 = smem + ((g0 + 0) & 7) * 16384;
+    const char* sB0 = smem + ((g0 + 1) & 7) * 16384;
+    const char* sB1 = smem + ((g0 + 2) & 7) * 16384;
+    const char* sA1 = smem + ((g0 + 3) & 7) * 16384;
+    // ---- phase 0: a0, b0 ; quadrant (0, 0)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b0[q] = *(const u32x4*)(sB0 + rdB[q]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) af[i][q] = *(const u32x4*)(sA0 + rdA[q] + i * 4096);
+    if (g0 + 6 < H) { issue(g0 + 6); wait_vm<8>(); } else wait_vm<0>();
+    raw_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) mma(af[i][q], b0[q], acc[i][0]);
+    __builtin_amdgcn_s_setprio(0);
+    raw_barrier();
+    // ---- phase 1: b1 ; quadrant (0, 1)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b1[q] = *(const u32x4*)(sB1 + rdB[q]);
+    if (g0 + 7 < H) { issue(g0 + 7); wait_vm<8>(); } else wait_vm<0>();
+    raw_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) mma(af[i][q], b1[q], acc[i][1]);
+    __builtin_amdgcn_s_setprio(0);
+    raw_barrier();
+    // ---- phase 2: a1 ; quadrant (1, 1)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) af[i][q] = *(const u32x4*)(sA1 + rdA[q] + i * 4096);
+    if (g0 + 8 < H) { issue(g0 + 8); wait_vm<10>(); } else wait_vm<0>();
+    raw_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) mma(af[i][q], b1[q], acc[2 + i][1]);
+    __builtin_amdgcn_s_setprio(0);
+    raw_barrier();
+    // ---- phase 3: nothing new ; quadrant (1, 0)
+    if (g0 + 9 < H) { issue(g0 + 9); wait_vm<8>(); } else wait_vm<0>();
+    raw_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) mma(af[i][q], b0[q], acc[2 + i][0]);
+    __builtin_amdgcn_s_setprio(0);
+    raw_barrier();
+  }
+  if (wm == 0) raw_barrier();
+  __syncthreads();
+#include "conv_gemm_epilogue.inc"
+}
+
+// false = shape not taken (the caller goes on to the one-stage kernel)
+bool launch_pipe_gemm(const KArgs& a, hipStream_t st) {
+  const ConvGeom& g = a.g;
+  const bool pw = g.k == 1 && g.stride == 1 && g.pad == 0 && g.groups == 1;
+  if (!pipe_kernels_enabled() || !pw || g.prec != 0 || g.kc < MDD_PIPE_MIN || g.nc < MDD_PIPE_MIN || (g.kc & 63) || (g.nc & 7) || (g.ca_tot & 7) ||
+      (g.co_tot & 7) || a.M < 8192 || a.ep.ib != nullptr || (int64_t)a.M * g.ca_tot * 2 >= (1ll << 31) ||
+      (int64_t)g.nc * g.kc * 2 >= (1ll << 31))
+    return false;
+  KArgs k = a;
+  k.mtiles = (a.M + 255) / 256;
+  k.ntiles = (g.nc + 255) / 256;
+  k.dbg = 0;
+  static std::atomic<uint64_t> attr_devs{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
+    if (hipFuncSetAttribute((const void*)k_gemm_pipe<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_gemm_pipe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess)
+      return false;
+    attr_devs.fetch_or(bit, std::memory_order_release);
+  }
+  const unsigned blocks = (unsigned)(k.mtiles * k.ntiles);
+  if (a.ep.act == 1) k_gemm_pipe<1><<<blocks, 512, 131072, st>>>(k);
+  else k_gemm_pipe<0><<<blocks, 512, 131072, st>>>(k);
+  return true;
+}
 
 template <class AT, int WGM, int WGN, int TM, int TN, int MODE, bool KFULL, int PREC, bool IBK = false, int ACT = 0>
 void launch_cfg(const KArgs& a, hipStream_t st) {
@@ -830,6 +835,9 @@ void launch_conv_gemm(const ConvGeom& g, const AT* A1, const AT* B1, const AT* A
     }                                                                                         \
     MDD_DISPATCH_P(WGM, WGN, TM, TN, 0);                                                      \
   } while (0)
+  if constexpr (sizeof(AT) == 2) {
+    if (launch_pipe_gemm(a, st)) return;
+  }
   if (ep.act == 1) {
     // exact-GELU epilogues (ViT MLP): own instances of the 128 x 128 pointwise kernel, so that the erf path's
     // registers do not weigh on the SiLU instances (a run-time switch cost the NFNet iteration +10 %, round 2);
@@ -855,6 +863,9 @@ void launch_conv_gemm(const ConvGeom& g, const AT* A1, const AT* B1, const AT* A
 #undef MDD_DISPATCH_P
 }
 // GELU epilogues: pointwise contractions on the 128 x 128 tile (output width per group > 64)
+static std::atomic<int> g_pipe_on{1};
+bool pipe_kernels_enabled() { return g_pipe_on.load(std::memory_order_relaxed) != 0; }
+void set_pipe_kernels(bool on) { g_pipe_on.store(on ? 1 : 0, std::memory_order_relaxed); }
 bool conv_gemm_supports_gelu(const ConvGeom& g) {
   return g.k == 1 && g.stride == 1 && g.pad == 0 && g.groups == 1 && g.nc > 64;
 }

@@ -764,7 +764,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_pipe(const WArgs p) {
 bool launch_pipe(WArgs a, float* slab, int64_t slab_floats, hipEvent_t ev_mid, hipStream_t st) {
   const ConvGeom& g = a.g;
   const bool pw = g.k == 1 && g.stride == 1 && g.pad == 0 && g.groups == 1;
-  if (!pw || g.nc < MDD_WG_PIPE_MIN || g.kc < MDD_WG_PIPE_MIN || (g.kc & 7) || (g.nc & 7) || (g.co_tot & 7) || (g.ca_tot & 7) ||
+  if (!pipe_kernels_enabled() || !pw || g.nc < MDD_WG_PIPE_MIN || g.kc < MDD_WG_PIPE_MIN || (g.kc & 7) || (g.nc & 7) || (g.co_tot & 7) || (g.ca_tot & 7) ||
       a.M < 2048)
     return false;
   const int ktot = g.kc;

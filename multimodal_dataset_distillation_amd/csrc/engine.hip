@@ -1645,6 +1645,11 @@ extern "C" {
 
 const char* mdd_last_error(void) { return g_err.c_str(); }
 int mdd_version(void) { return MDD_ABI_VERSION; }
+int mdd_set_pipe_kernels(int enable) {
+  const int prev = pipe_kernels_enabled() ? 1 : 0;
+  set_pipe_kernels(enable != 0);
+  return prev;
+}
 
 int mdd_engine_create(const mdd_config* cfg, mdd_engine** out) {
   CHECK_ARG(cfg && out && cfg->variant, "null config");

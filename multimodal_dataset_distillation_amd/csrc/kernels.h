@@ -91,7 +91,11 @@ struct ConvGeom {
 template <class AT>
 void launch_conv_gemm(const ConvGeom& g, const AT* A1, const AT* B1, const AT* A2, const AT* B2,
                       const ConvEpi& ep, hipStream_t st);
-bool conv_gemm_supports_gelu(const ConvGeom& g);   // ConvEpi::act == 1 may be requested for this geometry
+bool conv_gemm_supports_gelu(const ConvGeom& g);
+// the 256 x 256 pipelined kernels (k_gemm_pipe, k_wgrad_pipe) may be switched off at run time: the parity tests compare
+// an iteration with and without them (mdd_set_pipe_kernels)
+bool pipe_kernels_enabled();
+void set_pipe_kernels(bool on);   // ConvEpi::act == 1 may be requested for this geometry
 
 // ---------------------------------------------------------------- conv_wgrad.hip
 // dW[g][co][tap][kc] = sum_m dy[m][g*nc+co] * x[src(m,tap)][g*kc+kc], split over M.

@@ -29,6 +29,9 @@ CASES = [
     (5, 14, 192, 192, 3, 1, 3),
     (3, 28, 128, 128, 3, 1, 2),
     (2, 56, 64, 64, 3, 1, 1),
+    # wide pointwise layer with >= 8192 rows: in bf16 the 256 x 256 pipelined kernels (k_gemm_pipe forward and data
+    # gradient, k_wgrad_pipe); 8450 rows and 832 channels are not multiples of the tile
+    (2, 65, 512, 832, 1, 1, 1),
 ]
 
 

@@ -139,6 +139,61 @@ def test_vit_outer_iteration_matches_the_oracle(variant, nq, batch, size, d_txt,
     eng.close()
 
 
+def test_vit_b16_pipelined_contractions(report):
+    """The 256 x 256-tile pipelined kernels (csrc/conv_gemm.hip k_gemm_pipe with every fused epilogue of the four passes,
+    csrc/conv_wgrad.hip k_wgrad_pipe with one and two operand pairs) only take contractions of >= 8192 rows: ViT-B/16 at
+    42 pairs (8274 token rows, not a multiple of the 256-row tile or the 64-row K-tile).  One bf16 iteration with them
+    against (a) the same iteration on the general kernels (mdd_set_pipe_kernels(0)): same operands, other summation
+    order, and (b) the f32-mode engine, which the oracle tests above pin."""
+    from multimodal_dataset_distillation_amd import _lib
+    from multimodal_dataset_distillation_amd.engine import UnrollEngine
+    lib = _lib.load()
+    n, size, d_txt = 42, 224, 32
+    fi, ft = make_oracle("vit_b16", size, d_txt, 5)
+    g = torch.Generator().manual_seed(6)
+    img, txt = torch.randn(n, 3, size, size, generator=g), 0.5 * torch.randn(n, d_txt, generator=g)
+    th0i, th0t = fi.flat_param().detach(), ft.flat_param().detach()
+    perms = torch.stack([torch.randperm(n, generator=g)])
+    ni, nt_ = torch.randn(th0i.shape, generator=g), torch.randn(th0t.shape, generator=g)
+    outs = {}
+
+    def run(eng, tgi, tgt):
+        lr = torch.tensor([0.1, 0.07], device=DEV)
+        o = eng.unrolled_match(img.to(DEV), txt.to(DEV), lr[0:1], lr[1:2], th0i.to(DEV), th0t.to(DEV), tgi.to(DEV),
+                               tgt.to(DEV), perms=perms.to(DEV))
+        torch.cuda.synchronize()
+        return {k: o[k].detach().float().cpu().clone() for k in ("grand_loss", "img_loss", "txt_loss", "contrastive",
+                                                                  "image_syn", "text_syn", "lr")}
+    try:
+        # targets at a distance of the order of one inner step, as the oracle cases above (a target much further away
+        # makes the matching loss 1 + noise): |inner gradient| from a trial with a target so close that
+        # loss = lr^2 |g|^2 / |theta0 - target|^2
+        eng = UnrollEngine("vit_b16", batch=n, num_queries=n, image_size=size, d_txt=d_txt, syn_steps=1, dtype="f32")
+        t = run(eng, th0i + 1e-7 * ni, th0t + 1e-7 * nt_)
+        gn_i = float(t["img_loss"]) ** 0.5 * float((1e-7 * ni).norm()) / 0.1
+        gn_t = float(t["txt_loss"]) ** 0.5 * float((1e-7 * nt_).norm()) / 0.07
+        tgi = th0i + (0.1 * gn_i / th0i.numel() ** 0.5) * ni
+        tgt = th0t + (0.07 * gn_t / th0t.numel() ** 0.5) * nt_
+        outs["f32"] = run(eng, tgi, tgt)
+        eng.close()
+        assert abs(float(outs["f32"]["grand_loss"]) - 2.0) > 0.05
+        for tag, pipe in (("pipe", 1), ("general", 0), ("general again", 0)):
+            lib.mdd_set_pipe_kernels(pipe)
+            eng = UnrollEngine("vit_b16", batch=n, num_queries=n, image_size=size, d_txt=d_txt, syn_steps=1, dtype="bf16")
+            outs[tag] = run(eng, tgi, tgt)
+            eng.close()
+    finally:
+        lib.mdd_set_pipe_kernels(1)
+    for mine, ref, tol_s, tol_g in (("general again", "general", 2e-3, 2e-2), ("pipe", "general", 2e-3, 2e-2), ("pipe", "f32", 5e-3, 3e-2)):
+        a, b = outs[mine], outs[ref]
+        e = dict(grand=abs(a["grand_loss"].item() - b["grand_loss"].item()) / abs(b["grand_loss"].item()),
+                 ces=rel_err(a["contrastive"], b["contrastive"]), g_img=rel_err(a["image_syn"], b["image_syn"]),
+                 g_txt=rel_err(a["text_syn"], b["text_syn"]), g_lr=rel_err(a["lr"], b["lr"]))
+        report(f"vit_b16 n={n} bf16 {mine} vs {ref}: " + " ".join(f"{k} {float(v):.2e}" for k, v in e.items()))
+        assert float(e["grand"]) < tol_s and float(e["ces"]) < tol_s, (ref, e)
+        assert float(e["g_img"]) < tol_g and float(e["g_txt"]) < tol_g and float(e["g_lr"]) < tol_g, (ref, e)
+
+
 def test_vit_through_the_stage1_and_stage2_drivers(report, tmp_path):
     """`--image_encoder vit_micro --text_encoder clip` (512-d text embeddings) through buffer.py -> files in the
     reference's layout -> distill.py, the same route the NFNet encoders take (reference buffer.py:104-112,
