@@ -586,6 +586,11 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
 #ifndef MDD_PIPE_MIN
 #define MDD_PIPE_MIN 512     // narrowest layer (K and output channels) taken by k_gemm_pipe
 #endif
+#ifndef MDD_PIPE_ACT1
+#define MDD_PIPE_ACT1 1      // 1: the GELU-epilogue launches (fc1 forward, fc2 data gradient: 3072-wide outputs, two to five
+                             // stashed tensors per output tile) run on k_gemm_pipe too.  Per-launch it looks slower -- with one block
+                             // per CU nothing overlaps those HBM-bound epilogues (312 vs 232 us per launch inside configs[4]) -- but the iteration is faster with it (426 vs 445 ms): 0 is kept for the record
+#endif
 template <int N_> DEVI void wait_vm() {
   __builtin_amdgcn_s_waitcnt((N_ & 0xF) | ((N_ >> 4) << 14) | (0x7 << 4) | (0xF << 8));
 }
@@ -734,6 +739,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pipe(const KArgs p) {
 bool launch_pipe_gemm(const KArgs& a, hipStream_t st) {
   const ConvGeom& g = a.g;
   const bool pw = g.k == 1 && g.stride == 1 && g.pad == 0 && g.groups == 1;
+  if (!MDD_PIPE_ACT1 && a.ep.act == 1) return false;
   if (!pipe_kernels_enabled() || !pw || g.prec != 0 || g.kc < MDD_PIPE_MIN || g.nc < MDD_PIPE_MIN || (g.kc & 63) || (g.nc & 7) || (g.ca_tot & 7) ||
       (g.co_tot & 7) || a.M < 8192 || a.ep.ib != nullptr || (int64_t)a.M * g.ca_tot * 2 >= (1ll << 31) ||
       (int64_t)g.nc * g.kc * 2 >= (1ll << 31))

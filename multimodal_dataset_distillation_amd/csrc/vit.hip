@@ -19,6 +19,11 @@
 #define MDD_VIT_MFMA_ATTENTION 1   // bf16 storage: attention contractions on v_mfma_f32_32x32x16_bf16 (0: the S-generic FMA kernel)
 #endif
 
+#ifndef MDD_LN_BWD_ROWS
+#define MDD_LN_BWD_ROWS 16   // rows per block of k_ln_bwd (four waves, one row per wave at a time): the parameter-gradient sums cost
+                             // one fp32 atomic per column and block
+#endif
+
 namespace {
 
 template <class AT> DEVI void ldc(const AT* p, int64_t ci, float* f) {
@@ -758,7 +763,7 @@ int ln_bwd(int rows, int dim, float eps, const void* x, const void* x_t, const v
            const float* g, const float* g_t, const void* res, const void* res_t, void* dx, void* dx_t, float* dg,
            float* dg_t, float* db, float* db_t, hipStream_t st) {
   const int cch = dim / Chunk<AT>::N, maxc = (cch + 63) / 64;
-  const int rpb = 64, grid = (rows + rpb - 1) / rpb;
+  const int rpb = MDD_LN_BWD_ROWS, grid = (rows + rpb - 1) / rpb;
 #define LN_B(MC)                                                                                                 \
   do {                                                                                                           \
     if (x_t) k_ln_bwd<Dual, AT, MC><<<grid, 256, 0, st>>>((const AT*)x, (const AT*)x_t, (const AT*)dy,            \

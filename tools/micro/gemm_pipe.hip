@@ -269,6 +269,273 @@ __global__ __launch_bounds__(512, 1) void k_pipe(const bf16* __restrict__ A, con
   store_tile<4, 68>(acc, smem, C, M, N, m0, n0, wm, wn, lane, wave);
 }
 
+template <int STAGGER>
+__global__ __launch_bounds__(512, 1) void k_pipe_ld(const bf16* __restrict__ A, const bf16* __restrict__ B,
+                                                 bf16* __restrict__ C, int M, int N, int K, int ld) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
+  const int ntn = (N + 255) / 256;
+  int bid;
+  { const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3); }
+  const int nt = bid % ntn, mt = bid / ntn, m0 = mt * 256, n0 = nt * 256;
+  const int l31 = lane & 31, lh = lane >> 5;
+  // loader: per half-tile two 1-KB wave instructions; instruction j covers LDS rows j*64 + wave*8 + (lane>>3),
+  // this lane's 16-byte slot lane&7 receives global chunk slot ^ swizzle(row)
+  unsigned aoff[2][2], boff[2][2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = j * 64 + wave * 8 + (lane >> 3);
+      const int ch = (lane & 7) ^ ((r >> 1) & 7);
+      int m = m0 + (r >> 6) * 128 + hh * 64 + (r & 63); if (m >= M) m = M - 1;
+      int n = n0 + (r >> 5) * 64 + hh * 32 + (r & 31); if (n >= N) n = N - 1;
+      aoff[hh][j] = (unsigned)((m * ld + ch * 8) * 2);
+      boff[hh][j] = (unsigned)((n * ld + ch * 8) * 2);
+    }
+  // fragment read offsets inside a half-tile slot: A rows wm*64 + i*32 + l31 ; B rows wn*32 + l31
+  int rdA[4], rdB[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int ra_ = wm * 64 + l31, rb_ = wn * 32 + l31;
+    rdA[q] = ra_ * 128 + (((2 * q + lh) ^ ((ra_ >> 1) & 7)) << 4);
+    rdB[q] = rb_ * 128 + (((2 * q + lh) ^ ((rb_ >> 1) & 7)) << 4);
+  }
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int nk = K / 64, H = 4 * nk;
+  typedef const void __attribute__((address_space(1)))* gptr_t;
+  typedef void __attribute__((address_space(3)))* lptr_t;
+  // half-tile h = 4*kt + {0: A0, 1: B0, 2: B1, 3: A1} -> ring slot h & 7
+  auto issue = [&](int h) {
+    const int kt = h >> 2, jj = h & 3;
+    char* dst = smem + (h & 7) * 16384 + wave * 1024;
+    const char* src = (jj == 0 || jj == 3) ? (const char*)A : (const char*)B;
+    const int hh = (jj >= 2) ? 1 : 0;
+    const unsigned o0 = (jj == 0 || jj == 3) ? aoff[hh][0] : boff[hh][0];
+    const unsigned o1 = (jj == 0 || jj == 3) ? aoff[hh][1] : boff[hh][1];
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)kt * 128 + o0), (lptr_t)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)kt * 128 + o1), (lptr_t)(dst + 8192), 16, 0, 0);
+  };
+#pragma unroll
+  for (int h = 0; h < 6; ++h) issue(h);       // K >= 128: at least eight half-tiles exist
+  wait_vm<8>();                                // A0, B0 of K-tile 0 have landed (this wave's share)
+  asm volatile("s_barrier" ::: "memory");
+  if (STAGGER && wm == 1) asm volatile("s_barrier" ::: "memory");
+  u32x4 af[2][4], b0[4], b1[4];
+  for (int kt = 0; kt < nk; ++kt) {
+    const int g0 = 4 * kt;
+    const char* sA0 = smem + ((g0 + 0) & 7) * 16384;
+    const char* sB0 = smem + ((g0 + 1) & 7) * 16384;
+    const char* sB1 = smem + ((g0 + 2) & 7) * 16384;
+    const char* sA1 = smem + ((g0 + 3) & 7) * 16384;
+    // ---- phase 0: a0, b0 ; quadrant (0,0)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b0[q] = *(const u32x4*)(sB0 + rdB[q]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) af[i][q] = *(const u32x4*)(sA0 + rdA[q] + i * 4096);
+    if (g0 + 6 < H) { issue(g0 + 6); wait_vm<8>(); } else wait_vm<0>();
+    asm volatile("s_barrier" ::: "memory");
+    wait_lgkm0();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) mma(af[i][q], b0[q], acc[i][0]);
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_barrier" ::: "memory");
+    // ---- phase 1: b1 ; quadrant (0,1)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b1[q] = *(const u32x4*)(sB1 + rdB[q]);
+    if (g0 + 7 < H) { issue(g0 + 7); wait_vm<8>(); } else wait_vm<0>();
+    asm volatile("s_barrier" ::: "memory");
+    wait_lgkm0();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) mma(af[i][q], b1[q], acc[i][1]);
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_barrier" ::: "memory");
+    // ---- phase 2: a1 ; quadrant (1,1)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) af[i][q] = *(const u32x4*)(sA1 + rdA[q] + i * 4096);
+    if (g0 + 8 < H) { issue(g0 + 8); wait_vm<10>(); } else wait_vm<0>();
+    asm volatile("s_barrier" ::: "memory");
+    wait_lgkm0();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) mma(af[i][q], b1[q], acc[2 + i][1]);
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_barrier" ::: "memory");
+    // ---- phase 3: nothing new ; quadrant (1,0)
+    if (g0 + 9 < H) { issue(g0 + 9); wait_vm<8>(); } else wait_vm<0>();
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) mma(af[i][q], b0[q], acc[2 + i][0]);
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_barrier" ::: "memory");
+  }
+  if (STAGGER && wm == 0) asm volatile("s_barrier" ::: "memory");
+  __syncthreads();
+  store_tile<4, 68>(acc, smem, C, M, N, m0, n0, wm, wn, lane, wave);
+}
+
+template <int STAGGER>
+__global__ __launch_bounds__(512, 1) void k_pipe2(const bf16* __restrict__ A, const bf16* __restrict__ B,
+                                                 bf16* __restrict__ C, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
+  const int ntn = (N + 255) / 256;
+  int bid;
+  { const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3); }
+  const int nt = bid % ntn, mt = bid / ntn, m0 = mt * 256, n0 = nt * 256;
+  const int l31 = lane & 31, lh = lane >> 5;
+  // loader: per half-tile two 1-KB wave instructions; instruction j covers LDS rows j*64 + wave*8 + (lane>>3),
+  // this lane's 16-byte slot lane&7 receives global chunk slot ^ swizzle(row)
+  unsigned aoff[2][2], boff[2][2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = j * 64 + wave * 8 + (lane >> 3);
+      const int ch = (lane & 7) ^ ((r >> 1) & 7);
+      int m = m0 + (r >> 6) * 128 + hh * 64 + (r & 63); if (m >= M) m = M - 1;
+      int n = n0 + (r >> 5) * 64 + hh * 32 + (r & 31); if (n >= N) n = N - 1;
+      aoff[hh][j] = (unsigned)((m * K + ch * 8) * 2);
+      boff[hh][j] = (unsigned)((n * K + ch * 8) * 2);
+    }
+  // fragment read offsets inside a half-tile slot: A rows wm*64 + i*32 + l31 ; B rows wn*32 + l31
+  int rdA[4], rdB[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int ra_ = wm * 64 + l31, rb_ = wn * 32 + l31;
+    rdA[q] = ra_ * 128 + (((2 * q + lh) ^ ((ra_ >> 1) & 7)) << 4);
+    rdB[q] = rb_ * 128 + (((2 * q + lh) ^ ((rb_ >> 1) & 7)) << 4);
+  }
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int nk = K / 64, H = 4 * nk;
+  typedef const void __attribute__((address_space(1)))* gptr_t;
+  typedef void __attribute__((address_space(3)))* lptr_t;
+  // half-tile h = 4*kt + {0: B0, 1: A0, 2: B1, 3: A1} -> ring slot h & 7; phase g reads half-tile g + 1
+  auto issue = [&](int h) {
+    const int kt = h >> 2, jj = h & 3;
+    char* dst = smem + (h & 7) * 16384 + wave * 1024;
+    const bool isa = jj & 1;
+    const char* src = isa ? (const char*)A : (const char*)B;
+    const int hh = (jj >= 2) ? 1 : 0;
+    const unsigned o0 = isa ? aoff[hh][0] : boff[hh][0];
+    const unsigned o1 = isa ? aoff[hh][1] : boff[hh][1];
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)kt * 128 + o0), (lptr_t)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)kt * 128 + o1), (lptr_t)(dst + 8192), 16, 0, 0);
+  };
+#pragma unroll
+  for (int h = 0; h < 6; ++h) issue(h);       // K >= 128: at least eight half-tiles exist
+  wait_vm<10>();                               // B0 of K-tile 0 has landed (this wave's share)
+  asm volatile("s_barrier" ::: "memory");
+  u32x4 af[2][4], bx[4], by[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bx[q] = *(const u32x4*)(smem + rdB[q]);     // pre-phase: b0 of K-tile 0 (slot 0)
+  wait_vm<8>();                                // A0 of K-tile 0
+  asm volatile("s_barrier" ::: "memory");
+  if (STAGGER && wm == 1) asm volatile("s_barrier" ::: "memory");
+  // one K-tile; bcur holds b0 of this K-tile, bnxt receives b1 and then b0 of the next K-tile
+  auto ktile = [&](int kt, u32x4 (&bcur)[4], u32x4 (&bnxt)[4]) __attribute__((always_inline)) {
+    const int g0 = 4 * kt;
+    const char* sA0 = smem + ((g0 + 1) & 7) * 16384;
+    const char* sB1 = smem + ((g0 + 2) & 7) * 16384;
+    const char* sA1 = smem + ((g0 + 3) & 7) * 16384;
+    const char* sBn = smem + ((g0 + 4) & 7) * 16384;
+    // ---- phase 0: a0 ; quadrant (0,0)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) af[i][q] = *(const u32x4*)(sA0 + rdA[q] + i * 4096);
+    if (g0 + 6 < H) { issue(g0 + 6); wait_vm<8>(); } else wait_vm<0>();
+    asm volatile("s_barrier" ::: "memory");
+    wait_lgkm0();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) mma(af[i][q], bcur[q], acc[i][0]);
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_barrier" ::: "memory");
+    // ---- phase 1: b1 ; quadrant (0,1)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bnxt[q] = *(const u32x4*)(sB1 + rdB[q]);
+    if (g0 + 7 < H) { issue(g0 + 7); wait_vm<8>(); } else wait_vm<0>();
+    asm volatile("s_barrier" ::: "memory");
+    wait_lgkm0();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) mma(af[i][q], bnxt[q], acc[i][1]);
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_barrier" ::: "memory");
+    // ---- phase 2: a1 ; quadrant (1,1)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) af[i][q] = *(const u32x4*)(sA1 + rdA[q] + i * 4096);
+    if (g0 + 8 < H) { issue(g0 + 8); wait_vm<8>(); } else wait_vm<0>();
+    asm volatile("s_barrier" ::: "memory");
+    wait_lgkm0();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) mma(af[i][q], bnxt[q], acc[2 + i][1]);
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_barrier" ::: "memory");
+    // ---- phase 3: b0 of the next K-tile (into the registers b1 has left) ; quadrant (1,0)
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bnxt[q] = *(const u32x4*)(sBn + rdB[q]);
+    }
+    if (g0 + 9 < H) { issue(g0 + 9); wait_vm<8>(); } else wait_vm<0>();
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) mma(af[i][q], bcur[q], acc[2 + i][0]);
+    __builtin_amdgcn_s_setprio(0);
+    wait_lgkm0();
+    asm volatile("s_barrier" ::: "memory");
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    ktile(kt, bx, by);
+    if (kt + 1 < nk) ktile(kt + 1, by, bx);
+  }
+  if (STAGGER && wm == 0) asm volatile("s_barrier" ::: "memory");
+  __syncthreads();
+  store_tile<4, 68>(acc, smem, C, M, N, m0, n0, wm, wn, lane, wave);
+}
+
 // =============================================================== host
 static void check(hipError_t e, const char* w) { if (e != hipSuccess) { printf("HIP error %s: %s\n", w, hipGetErrorString(e)); exit(1); } }
 
@@ -302,14 +569,23 @@ int main() {
     hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice);
     hipMemcpy(B, hb.data(), hb.size() * 2, hipMemcpyHostToDevice);
     const double fl = 2.0 * M * K * N;
+    const int ld = K + 64;                      // row stride + one 128-byte line: consecutive rows land on different L2 channels
+    bf16 *Ap, *Bp;
+    check(hipMalloc(&Ap, (size_t)M * ld * 2), "malloc"); check(hipMalloc(&Bp, (size_t)N * ld * 2), "malloc");
+    hipMemcpy2D(Ap, (size_t)ld * 2, A, (size_t)K * 2, (size_t)K * 2, M, hipMemcpyDeviceToDevice);
+    hipMemcpy2D(Bp, (size_t)ld * 2, B, (size_t)K * 2, (size_t)K * 2, N, hipMemcpyDeviceToDevice);
     struct Var { const char* name; std::function<float()> run; float best; };
     std::vector<Var> vars;
     const int g1 = ((M + 127) / 128) * ((N + 127) / 128), g2 = ((M + 255) / 256) * ((N + 255) / 256);
     hipFuncSetAttribute((const void*)k_reg, hipFuncAttributeMaxDynamicSharedMemorySize, 34816);
     hipFuncSetAttribute((const void*)k_pipe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     hipFuncSetAttribute((const void*)k_pipe<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipFuncSetAttribute((const void*)k_pipe_ld<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipFuncSetAttribute((const void*)k_pipe2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     vars.push_back({"REG 128x128", [&] { return timeit([&] { k_reg<<<g1, 256, 34816>>>(A, B, Cref, M, N, K); }); }, 1e30f});
     vars.push_back({"PIPE 256x256 pingpong", [&] { return timeit([&] { k_pipe<1><<<g2, 512, 131072>>>(A, B, C, M, N, K); }); }, 1e30f});
+    vars.push_back({"PIPE2 balanced reads", [&] { return timeit([&] { k_pipe2<1><<<g2, 512, 131072>>>(A, B, C, M, N, K); }); }, 1e30f});
+    vars.push_back({"PIPE row stride K+64", [&] { return timeit([&] { k_pipe_ld<1><<<g2, 512, 131072>>>(Ap, Bp, C, M, N, K, ld); }); }, 1e30f});
     vars.push_back({"PIPE 256x256 lockstep", [&] { return timeit([&] { k_pipe<0><<<g2, 512, 131072>>>(A, B, C, M, N, K); }); }, 1e30f});
     for (int round = 0; round < 3; ++round)
       for (auto& v : vars) { float t = v.run(); if (t < v.best) v.best = t; }
@@ -332,7 +608,7 @@ int main() {
       if (i) printf("   max|diff vs REG| %.3g  bad %zu", maxd, bad);
       printf("\n");
     }
-    hipFree(A); hipFree(B); hipFree(C); hipFree(Cref);
+    hipFree(A); hipFree(B); hipFree(C); hipFree(Cref); hipFree(Ap); hipFree(Bp);
   }
   return 0;
 }
