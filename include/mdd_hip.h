@@ -69,7 +69,7 @@ const char* mdd_last_error(void);
  * must refuse to load. */
 #define MDD_ABI_VERSION 6
 int mdd_version(void);
-/* The wide bf16 pointwise contractions (>= 512 channels in and out, >= 8192 rows: the ViT linears) run on 256 x 256-tile
+/* The wide bf16 pointwise contractions (>= 768 channels in and out, >= 8192 rows: the ViT linears) run on 256 x 256-tile
  * pipelined kernels; 0 routes them to the general kernels instead (process-wide; returns the previous setting).  For the
  * parity tests, which compare an iteration both ways, and for A/B timing. */
 int mdd_set_pipe_kernels(int enable);

@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
 //     waves of a SIMD one issues MFMAs while the other reads LDS.  Hazard rules: see k_wgrad_pipe (conv_wgrad.hip).
 // Rows past M and columns past nc are clamped (computed, never stored).  The epilogue is the common one.
 #ifndef MDD_PIPE_MIN
-#define MDD_PIPE_MIN 512     // narrowest layer (K and output channels) taken by k_gemm_pipe
+#define MDD_PIPE_MIN 768     // narrowest layer (K and output channels) taken by k_gemm_pipe: the ViT linears; NFNet-l0's 512- and 1536-wide layers ran 0.6 % slower per iteration with it
 #endif
 #ifndef MDD_PIPE_ACT1
 #define MDD_PIPE_ACT1 1      // 1: the GELU-epilogue launches (fc1 forward, fc2 data gradient: 3072-wide outputs, two to five

@@ -39,7 +39,7 @@
 #define MDD_WG_MIN_WAVES 1
 #endif
 #ifndef MDD_WG_PIPE_MIN
-#define MDD_WG_PIPE_MIN 512  // narrowest layer (channels in and out) taken by the 256 x 256 pipelined kernel
+#define MDD_WG_PIPE_MIN 768  // narrowest layer (channels in and out) taken by the 256 x 256 pipelined kernel
 #endif
 #ifndef MDD_WGP_ABL
 #define MDD_WGP_ABL 0   // timing experiments on k_wgrad_pipe (wrong results): 1 no MFMAs, 2 no LDS-DMA, 4 no fragment reads, 8 no write-out
@@ -765,7 +765,7 @@ bool launch_pipe(WArgs a, float* slab, int64_t slab_floats, hipEvent_t ev_mid, h
   const ConvGeom& g = a.g;
   const bool pw = g.k == 1 && g.stride == 1 && g.pad == 0 && g.groups == 1;
   if (!pipe_kernels_enabled() || !pw || g.nc < MDD_WG_PIPE_MIN || g.kc < MDD_WG_PIPE_MIN || (g.kc & 7) || (g.nc & 7) || (g.co_tot & 7) || (g.ca_tot & 7) ||
-      a.M < 2048)
+      a.M < 8192)
     return false;
   const int ktot = g.kc;
   a.cotiles = (g.nc + 255) / 256;

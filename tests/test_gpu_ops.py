@@ -31,7 +31,7 @@ CASES = [
     (2, 56, 64, 64, 3, 1, 1),
     # wide pointwise layer with >= 8192 rows: in bf16 the 256 x 256 pipelined kernels (k_gemm_pipe forward and data
     # gradient, k_wgrad_pipe); 8450 rows and 832 channels are not multiples of the tile
-    (2, 65, 512, 832, 1, 1, 1),
+    (2, 65, 768, 832, 1, 1, 1),
 ]
 
 
@@ -108,7 +108,7 @@ def test_conv_ops(case, dtype, report):
 
 @pytest.mark.parametrize("pairs", [1, 2])
 @pytest.mark.parametrize("workspace", [False, True])
-@pytest.mark.parametrize("shape", [(2352, 768, 512), (2352, 520, 776), (4500, 1024, 768), (2100, 512, 1032)])
+@pytest.mark.parametrize("shape", [(8274, 768, 768), (8200, 776, 1032), (9000, 1024, 768), (8193, 768, 1032)])
 def test_wide_pointwise_wgrad(shape, workspace, pairs, report):
     """Weight gradient of wide pointwise layers in bf16 (the ViT linears: csrc/conv_wgrad.hip k_wgrad_pipe, 256 x 256
     tiles, LDS-DMA ring): one / two operand pairs, split-M workspace or atomics, channel counts that are not a

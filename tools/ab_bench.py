@@ -30,6 +30,8 @@ def one(lib_path, dtype, steps, workload, own_stream=False):
     dev = torch.device("cuda", 0)
     eng = UnrollEngine(variant, batch=n, num_queries=n, image_size=size, d_txt=d_txt, syn_steps=K, dtype=dtype, device=dev)
     lib = _lib.load()
+    if os.environ.get("AB_NO_PIPE"):          # A/B of the 256 x 256 pipelined kernels inside one build
+        lib.mdd_set_pipe_kernels(0)
     g = torch.Generator().manual_seed(0)
     image_syn = torch.randn(n, 3, size, size, generator=g).to(dev)
     text_syn = (torch.randn(n, d_txt, generator=g) * 0.5253).to(dev)

@@ -11,7 +11,7 @@ dev = "cuda"
 P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 torch.manual_seed(0)
 ws = torch.empty(16 * 3072 * 768, device=dev)
-shapes = [(2352, 768, 512), (2352, 520, 776), (19700, 768, 3072), (19700, 3072, 768), (19700, 768, 2304), (19700, 768, 768),
+shapes = [(8274, 768, 768), (8200, 776, 1032), (19700, 768, 3072), (19700, 3072, 768), (19700, 768, 2304), (19700, 768, 768),
           (19600, 1536, 384), (19600, 384, 1536), (4900, 1536, 2304)]
 for (M, cin, cout) in shapes:
     for two in (False, True):
