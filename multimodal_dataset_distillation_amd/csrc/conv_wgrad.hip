@@ -41,6 +41,9 @@
 #ifndef MDD_WG_PIPE_MIN
 #define MDD_WG_PIPE_MIN 768  // narrowest layer (channels in and out) taken by the 256 x 256 pipelined kernel
 #endif
+#ifndef MDD_WG_SLAB
+#define MDD_WG_SLAB 1     // grouped 3x3 stride-1 convolutions with 64-channel groups on k_wgrad_slab (all nine taps per pass)
+#endif
 #ifndef MDD_WGP_ABL
 #define MDD_WGP_ABL 0   // timing experiments on k_wgrad_pipe (wrong results): 1 no MFMAs, 2 no LDS-DMA, 4 no fragment reads, 8 no write-out
 #endif
@@ -760,6 +763,262 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_pipe(const WArgs p) {
   }
 }
 
+// ======================================================================================================
+// Grouped 3x3 stride-1 "same" convolutions with 64-channel groups (conv2 / conv2b of every NFNet block), bf16:
+// ALL nine taps from ONE pass over the pixels.  The general kernel tiles k' = (tap, channel) into 128-wide blocks, so a
+// group's 576 columns are 4.5 blocks that each re-read dy, and every tap is its own gather of x: 46 bytes through L1 per
+// kMAC against 31 for a pointwise layer.  Here a block owns (group, pixel chunk): the 64-channel dy rows go to LDS as in
+// the general kernel, the x rows [m - W - 1, m + 64 + W] live in a 256-row LDS RING that advances 64 pixels per step, and
+// tap (ty, tx) of pixel m is ring row m + (ty-1) W + (tx-1) -- or a row of zeros where the tap leaves the image (per-pixel
+// 9-bit mask, tracked incrementally): 16 KB of loads per step for 64 x 64 x 576 MACs = 7 bytes per kMAC.
+// Wave w owns input channels [16w, 16w+16) of every tap x all 64 output channels: 36 accumulator blocks of 16 x 16.
+__global__ __launch_bounds__(256, 2) void k_wgrad_slab(const WArgs p) {
+  constexpr int RING = 256;
+  __shared__ __attribute__((aligned(16))) char smem[64 * 128 + (RING + 1) * 128];
+  char* const Ds = smem;
+  char* const Xs = smem + 64 * 128;
+  const ConvGeom& G = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int grp, bsplit;
+  {
+    const int nwg = gridDim.x * gridDim.y, orig = blockIdx.x + blockIdx.y * gridDim.x;
+    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    bsplit = lin / gridDim.x;
+    grp = lin - bsplit * gridDim.x;
+  }
+  const int W = G.wo, H = G.ho;
+  const int mbeg = bsplit * p.mchunk;
+  const int mend = min(p.M, mbeg + p.mchunk);
+  const int rows = mend - mbeg;
+  const int niter = (rows + 63) >> 6;
+  constexpr unsigned OOB = 0x80000000u;
+  auto rsrc = [&](const void* base, int64_t elem_off) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + elem_off * 2), (short)0, 0x7fffffff, 0x00020000);
+  };
+  // staging: thread -> 16-byte chunk column scol of rows srow, srow + 32
+  const int scol = tid & 7, srow = tid >> 3;
+  const int wsw_s = ((srow >> 1) & 3) << 1;      // rows 32 apart share it
+  if (tid < 8) *(uint4*)(Xs + RING * 128 + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
+
+  // fragment geometry: lane (gq, q, pp); its four pixel positions of a 64-pixel step
+  const int gq = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+  int lp[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) lp[ks][e] = ks * 32 + 4 * (2 * (2 * e + (gq >> 1)) + (gq & 1)) + q;
+  const int dq64 = 64 / W, dr64 = 64 - dq64 * W;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+
+  f32x4 acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][i][r] = 0.f;
+  float bsum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+
+  auto run = [&](const void* dyp, const void* xp, const bool bias) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t rs_dy = rsrc(dyp, (int64_t)mbeg * G.co_tot + (int64_t)grp * 64);
+    const __amdgpu_buffer_rsrc_t rs_x = rsrc(xp, (int64_t)grp * 64);
+    // ---- prologue: x pixels [mbeg - W - 1, mbeg + 64 + W] -> ring rows 0 .., dy rows of step 0
+    const int org = mbeg - W - 1;                 // pixel of ring row 0 (mod RING)
+    const int npro = 66 + 2 * W;
+    for (int j0 = 0; j0 < npro; j0 += 32) {
+      const int j = j0 + srow, px = org + j;
+      const bool ok = j < npro && px >= 0 && px < p.M;
+      const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+          rs_x, (int)(ok ? (unsigned)((px * G.ca_tot) * 2 + scol * 16) : OOB), 0, 0));
+      if (j < npro) *(u32x4*)(Xs + (j & (RING - 1)) * 128 + ((scol ^ ((((j & (RING - 1)) >> 1) & 3) << 1)) << 4)) = v;
+    }
+    u32x4 rd[2], rx[2];
+    auto load_step = [&](int it) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = it * 64 + srow + 32 * i;
+        rd[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            rs_dy, (int)(r < rows ? (unsigned)((r * G.co_tot) * 2 + scol * 16) : OOB), 0, 0));
+      }
+    };
+    auto load_x = [&](int it) __attribute__((always_inline)) {     // the 64 new pixels step it needs beyond step it-1's
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int px = mbeg + it * 64 + W + 1 + srow + 32 * i;
+        rx[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            rs_x, (int)(px < p.M ? (unsigned)((px * G.ca_tot) * 2 + scol * 16) : OOB), 0, 0));
+      }
+    };
+    auto store_dy = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        *(u32x4*)(Ds + (srow + 32 * i) * 128 + ((scol ^ wsw_s) << 4)) = rd[i];
+        if (bias) {
+          float f[8];
+          Chunk<bf16>::unpack(__builtin_bit_cast(uint4, rd[i]), f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bsum[e] += f[e];
+        }
+      }
+    };
+    auto store_x = [&](int it) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int rr = (it * 64 + 2 * W + 2 + srow + 32 * i) & (RING - 1);       // = pixel - org
+        *(u32x4*)(Xs + rr * 128 + ((scol ^ (((rr >> 1) & 3) << 1)) << 4)) = rx[i];
+      }
+    };
+    // running (oy, ox) of this lane's four pixel positions
+    int oy[2][2], ox[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int m = mbeg + lp[ks][e];
+        ox[ks][e] = m % W;
+        oy[ks][e] = (m / W) % H;
+      }
+    if (niter > 0) { load_step(0); store_dy(); }
+    __syncthreads();
+    for (int it = 0; it < niter; ++it) {
+      if (it + 1 < niter) { load_step(it + 1); load_x(it + 1); }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        s16x8 a8[4];
+        unsigned tm[2];
+        int rb[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int row = lp[ks][e];
+          const unsigned ym = (oy[ks][e] > 0 ? 1u : 0u) | 2u | (oy[ks][e] < H - 1 ? 4u : 0u);
+          const unsigned xm = (ox[ks][e] > 0 ? 1u : 0u) | 2u | (ox[ks][e] < W - 1 ? 4u : 0u);
+          tm[e] = ((ym & 1u) ? xm : 0u) | ((ym & 2u) ? xm << 3 : 0u) | ((ym & 4u) ? xm << 6 : 0u);
+          rb[e] = it * 64 + W + 1 + row;          // ring row of the centre tap (before the mask)
+        }
+        s16x4 af[4][2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int row = lp[ks][e];
+          const int sw = ((row >> 1) & 3) << 2;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            af[i][e] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(Ds + row * 128 + (((4 * i + pp) ^ sw) << 3)));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a8[i] = __builtin_shufflevector(af[i][0], af[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+          s16x4 bf[3][2];
+#pragma unroll
+          for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const int t = ty * 3 + tx;
+              const int rr = (rb[e] + (ty - 1) * W + (tx - 1)) & (RING - 1);
+              const int off = ((tm[e] >> t) & 1u) ? rr * 128 + (((4 * wave + pp) ^ (((rr >> 1) & 3) << 2)) << 3)
+                                                  : RING * 128 + pp * 8;
+              bf[tx][e] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(Xs + off));
+            }
+#pragma unroll
+          for (int tx = 0; tx < 3; ++tx) {
+            const s16x8 b8 = __builtin_shufflevector(bf[tx][0], bf[tx][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              acc[ty * 3 + tx][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b8), __builtin_bit_cast(bf16x8, a8[i]),
+                                                                            acc[ty * 3 + tx][i], 0, 0, 0);
+          }
+        }
+      }
+      // advance the pixel positions by 64
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          ox[ks][e] += dr64; oy[ks][e] += dq64;
+          if (ox[ks][e] >= W) { ox[ks][e] -= W; ++oy[ks][e]; }
+          while (oy[ks][e] >= H) oy[ks][e] -= H;
+        }
+      __syncthreads();                   // every wave is done with the dy tile (and with ring rows older than this step's)
+      if (it + 1 < niter) { store_dy(); store_x(it + 1); }
+      __syncthreads();
+    }
+  };
+  run(p.dy1, p.x1, p.dbias != nullptr);
+  if (p.dy2) run(p.dy2, p.x2, false);
+
+  // ---- write-out: rows = k' (4 consecutive per lane), columns = co
+  const int ktot = 576;
+  const size_t gbase = (size_t)grp * 64 * ktot;
+  float* dst = p.slab ? p.slab + (size_t)bsplit * p.slab_stride + gbase : p.dW + gbase;
+  const bool plain = p.slab != nullptr;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float* a = dst + (size_t)(16 * i + li) * ktot + t * 64 + 16 * wave + 4 * gq;
+      if (plain) {
+        *(float4*)a = make_float4(acc[t][i][0], acc[t][i][1], acc[t][i][2], acc[t][i][3]);
+      } else {
+        atomicAdd(a, acc[t][i][0]); atomicAdd(a + 1, acc[t][i][1]); atomicAdd(a + 2, acc[t][i][2]); atomicAdd(a + 3, acc[t][i][3]);
+      }
+    }
+  if (p.dbias) {
+    __syncthreads();
+    float* sh = (float*)smem;      // [32 rows][8 chunk columns][8]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sh[(srow * 8 + scol) * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < 64) {
+      float s_ = 0.f;
+      for (int r = 0; r < 32; ++r) s_ += sh[(r * 8 + (tid >> 3)) * 8 + (tid & 7)];
+      atomicAdd(p.dbias + grp * 64 + tid, s_);
+    }
+  }
+}
+
+bool launch_slab(WArgs a, float* slab, int64_t slab_floats, hipEvent_t ev_mid, hipStream_t st) {
+  const ConvGeom& g = a.g;
+  if (!MDD_WG_SLAB || g.k != 3 || g.stride != 1 || g.pad != 1 || g.kc != 64 || g.nc != 64 || g.ha != g.ho || g.wa != g.wo ||
+      g.wo > 90 || g.wo < 3 || (g.ca_tot & 7) || (g.co_tot & 7) || (int64_t)a.M * std::max(g.ca_tot, g.co_tot) * 2 >= (1ll << 31))
+    return false;
+  const int nsrc = a.dy2 ? 2 : 1;
+  const int64_t out_floats = (int64_t)g.groups * 64 * 576;
+  const double out_mb = (double)out_floats * 4.0 / 1e6;
+  const bool two_phase = slab != nullptr && slab_floats >= out_floats && ((uintptr_t)a.dW & 15) == 0;
+  const double comb_us_per_mb = two_phase ? 0.6 : 1.0 / 1.3;
+  int maxsplits = std::max(1, a.M / 256);     // at least four steps per block
+  if (two_phase && maxsplits > slab_floats / out_floats) maxsplits = (int)(slab_floats / out_floats);
+  // step cost of the model from a sweep on MI355X (tools/micro/wgrad_slab_check.py): 1.2 us suits one operand pair, a
+  // tangent launch (two pairs) wants about twice the splits that figure gives
+  int splits = 1;
+  double best = 1e30;
+  for (int sp = 1; sp <= maxsplits; sp = sp < 32 ? sp + 1 : sp + sp / 16) {
+    const int chunk = ((a.M + sp - 1) / sp + 63) / 64 * 64;
+    const double steps = (double)nsrc * chunk / 64;
+    const double waves = (double)(((int64_t)g.groups * sp + 511) / 512);     // two blocks per CU
+    const double t = waves * (steps * (nsrc == 2 ? 5.0 : 1.2) + 6.0 * nsrc) + out_mb * sp * comb_us_per_mb;
+    if (t < best) { best = t; splits = sp; }
+  }
+  int mchunk = ((a.M + splits - 1) / splits + 63) / 64 * 64;
+  splits = (a.M + mchunk - 1) / mchunk;
+  a.mchunk = mchunk;
+  a.dbg = 0;
+  a.cotiles = a.kptiles = 1;
+  a.slab = two_phase ? slab : nullptr;
+  a.slab_stride = out_floats;
+  k_wgrad_slab<<<dim3(g.groups, splits), 256, 0, st>>>(a);
+  if (ev_mid) (void)hipEventRecord(ev_mid, st);
+  if (two_phase) {
+    const int64_t n4 = out_floats / 4;
+    k_wgrad_reduce<<<(unsigned)((n4 + 15) / 16), 256, 0, st>>>(a.dW, slab, n4, out_floats / 4, splits);
+  }
+  return true;
+}
+
 // split policy and launch of k_wgrad_pipe; false = shape not taken (the caller falls through to the one-stage kernel)
 bool launch_pipe(WArgs a, float* slab, int64_t slab_floats, hipEvent_t ev_mid, hipStream_t st) {
   const ConvGeom& g = a.g;
@@ -902,6 +1161,7 @@ void launch_conv_wgrad(const ConvGeom& g, const AT* dy1, const AT* x1, const AT*
   a.cotiles = a.kptiles = a.mchunk = 0;
   if constexpr (sizeof(AT) == 2) {
     if (launch_pipe(a, slab, slab_floats, ev_mid, st)) return;
+    if (launch_slab(a, slab, slab_floats, ev_mid, st)) return;
     if (g.nc > 64) launch_cfg<AT, 128, 128, MDD_WG_BKM>(a, slab, slab_floats, ev_mid, st);
     else launch_cfg<AT, 64, 128, MDD_WG_BKM>(a, slab, slab_floats, ev_mid, st);
   } else {
