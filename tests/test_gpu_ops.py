@@ -137,6 +137,45 @@ def test_wide_pointwise_wgrad(shape, workspace, pairs, report):
     assert e_w < 1e-5 and e_b < 1e-5
 
 
+@pytest.mark.parametrize("pairs", [1, 2])
+@pytest.mark.parametrize("workspace", [False, True])
+@pytest.mark.parametrize("shape", [(5, 14, 192), (3, 28, 128), (11, 7, 128), (2, 56, 64)])
+def test_grouped_3x3_wgrad_pairs(shape, workspace, pairs, report):
+    """Weight gradient of the grouped 3x3 stride-1 convolutions with 64-channel groups in bf16 (csrc/conv_wgrad.hip
+    k_wgrad_slab: the x rows of all nine taps from one LDS ring): the engine's form -- a second operand pair (tangent pass),
+    the split-M workspace -- at every feature-map width of NFNet-l0, chunks that straddle image boundaries.  Reference:
+    torch's conv2d weight gradient in fp32 on the same bf16 operands."""
+    from multimodal_dataset_distillation_amd import _lib
+    lib = _lib.load()
+    nimg, h, ch = shape
+    groups = ch // 64
+    dev = "cuda"
+    torch.manual_seed(nimg * h + pairs)
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    xs = [torch.randn(nimg, ch, h, h).bfloat16().float() for _ in range(pairs)]
+    dys = [torch.randn(nimg, ch, h, h).bfloat16().float() for _ in range(pairs)]
+    ref = torch.zeros(ch, 64, 3, 3)
+    for x, dy in zip(xs, dys):
+        w = torch.zeros(ch, 64, 3, 3, requires_grad=True)
+        (gw,) = torch.autograd.grad(F.conv2d(x, w, None, 1, 1, 1, groups), [w], dy)
+        ref += gw
+    rb = dys[0].sum((0, 2, 3))
+    xd = [nhwc(x).to(dev, torch.bfloat16) for x in xs]
+    dyd = [nhwc(d).to(dev, torch.bfloat16) for d in dys]
+    ws = torch.empty(40 * ch * 576, device=dev) if workspace else None
+    dw = torch.full((ch, 9, 64), float("nan"), device=dev) if workspace else torch.zeros(ch, 9, 64, device=dev)
+    db = torch.zeros(ch, device=dev)
+    _lib.check(lib.mdd_op_conv2d_wgrad2(1, nimg, h, h, ch, ch, 3, 1, 1, groups, P(dyd[0]), P(xd[0]),
+                                        P(dyd[1]) if pairs == 2 else None, P(xd[1]) if pairs == 2 else None,
+                                        P(dw), P(db), P(ws), ws.numel() if workspace else 0, st))
+    torch.cuda.synchronize()
+    got = dw.cpu().view(ch, 9, 64).permute(0, 2, 1).reshape(ch, 64, 3, 3)
+    e_w, e_b = rel_err(got, ref), rel_err(db.cpu(), rb)
+    report(f"grouped 3x3 wgrad bf16 {shape} pairs {pairs} workspace {workspace}: dW {e_w:.2e} bias {e_b:.2e}")
+    assert e_w < 1e-5 and e_b < 1e-5
+
+
 def test_flat_ops(report):
     from multimodal_dataset_distillation_amd import _lib
     lib = _lib.load()
