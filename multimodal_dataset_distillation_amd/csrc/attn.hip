@@ -22,6 +22,9 @@
 // product  out[owner, :] = sum_other W[owner, other] R[other, :]  (rows = owner = lane, eight `other` per lane), so the
 // probabilities / score gradients go from accumulator registers to the matrix cores without touching LDS; R (V, K, dO
 // or Q) is staged transposed in LDS so that a lane's eight `other` values of one column are two 8-byte reads.
+#include <atomic>
+#include <cstdint>
+
 #include "kernels.h"
 #include "mdd_hip.h"
 
@@ -459,10 +462,14 @@ template <int MODE> size_t attn_lds() {
 }
 template <int MODE> int attn_launch(const AttnArgs& a, hipStream_t st) {
   const size_t shm = attn_lds<MODE>();
-  static bool attr = false;
-  if (!attr) {
+  // the dynamic-LDS limit is a per-device function attribute: set it once per (instance, device)
+  static std::atomic<uint64_t> attr_devs{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)k_attn<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    attr = true;
+    attr_devs.fetch_or(bit, std::memory_order_release);
   }
   k_attn<MODE><<<dim3((unsigned)a.heads, (unsigned)a.n), 512, shm, st>>>(a);
   HIP_CHECK_RET(hipGetLastError());

@@ -155,6 +155,25 @@ DEVI Dual dgelu_(Dual x) {
   return Dual(dgelu_(x.v), phi * (2.f - x.v * x.v) * x.t);
 }
 
+// the same functions for bf16 storage (k_gemm_pipe's epilogues): Phi from the rational approximation of erf (Abramowitz &
+// Stegun 7.1.26, |error| < 1.5e-7: three orders below bf16's 2^-9) with ONE exp(-x^2/2) shared by Phi and phi -- the
+// library erff plus a second exponential were 19 ms of a 440 ms configs[4] iteration
+DEVI void gelu_parts_fast(float x, float& Phi, float& phi) {
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  const float e = __expf(-0.5f * x * x);                     // = exp(-(x / sqrt 2)^2)
+  const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  Phi = 0.5f * (1.f + copysignf(1.f - poly * e, x));
+  phi = 0.3989422804014327f * e;
+}
+DEVI float gelu_fast_(float x) { float Phi, phi; gelu_parts_fast(x, Phi, phi); return x * Phi; }
+DEVI float dgelu_fast_(float x) { float Phi, phi; gelu_parts_fast(x, Phi, phi); return Phi + x * phi; }
+DEVI Dual dgelu_fast_(Dual x) {
+  float Phi, phi;
+  gelu_parts_fast(x.v, Phi, phi);
+  return Dual(Phi + x.v * phi, phi * (2.f - x.v * x.v) * x.t);
+}
+
 // ------------------------------------------------------------------ wave / block reductions
 DEVI float wave_sum(float x) {
 #pragma unroll

@@ -174,10 +174,24 @@ struct KArgs {
   int M, mtiles, ntiles, dbg;
 };
 
+// orders one wave's own LDS accesses (its private epilogue staging): LDS executes a wave's instructions in order, so all
+// that is needed is that the compiler neither reorders them nor lets a read's result be used before it has returned
+DEVI void epi_wave_sync() {
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+}
+
 // activation of the fused epilogues: 0 = SiLU (NFNet), 1 = exact GELU (the ViT MLP: fc1's forward and fc2's data gradient)
-template <int ACT> DEVI float actf(float x) { if constexpr (ACT == 1) return gelu_(x); else return silu_(x); }
-template <int ACT> DEVI float dactf(float x) { if constexpr (ACT == 1) return dgelu_(x); else return dsilu_(x); }
-template <int ACT> DEVI Dual dactf(Dual x) { if constexpr (ACT == 1) return dgelu_(x); else return dsilu_(x); }
+// (2 = the same GELU through the 1.5e-7 erf approximation: bf16 storage only, k_gemm_pipe)
+template <int ACT> DEVI float actf(float x) {
+  if constexpr (ACT == 2) return gelu_fast_(x); else if constexpr (ACT == 1) return gelu_(x); else return silu_(x);
+}
+template <int ACT> DEVI float dactf(float x) {
+  if constexpr (ACT == 2) return dgelu_fast_(x); else if constexpr (ACT == 1) return dgelu_(x); else return dsilu_(x);
+}
+template <int ACT> DEVI Dual dactf(Dual x) {
+  if constexpr (ACT == 2) return dgelu_fast_(x); else if constexpr (ACT == 1) return dgelu_(x); else return dsilu_(x);
+}
 
 template <class AT, int WGM, int WGN, int TM, int TN, int MODE, bool KFULL, int PREC, bool IBK = false, int ACT = 0>
 __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p) {
@@ -185,6 +199,7 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
   constexpr int RA = BM / 32, RB = BN / 32;
   typedef typename MmaSel<AT, PREC>::type MT;
   constexpr int KE = MT::KE, CE = MT::CE;
+  constexpr bool EPI_WAVE_SYNC = false;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NBUF = MDD_SINGLE_BUF ? 1 : 2;   // LDS stages (registers hold the slab in flight)
 
@@ -586,6 +601,12 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
 #ifndef MDD_PIPE_MIN
 #define MDD_PIPE_MIN 768     // narrowest layer (K and output channels) taken by k_gemm_pipe: the ViT linears; NFNet-l0's 512- and 1536-wide layers ran 0.6 % slower per iteration with it
 #endif
+#ifndef MDD_PIPE_EPI_WAVE_SYNC
+#define MDD_PIPE_EPI_WAVE_SYNC 1   // k_gemm_pipe: the waves of a block run their epilogues independently (wave-private staging)
+#endif
+#ifndef MDD_PIPE_FAST_GELU
+#define MDD_PIPE_FAST_GELU 1   // k_gemm_pipe: GELU, GELU', GELU'' from the 1.5e-7 erf approximation with one shared exponential
+#endif
 #ifndef MDD_PIPE_ACT1
 #define MDD_PIPE_ACT1 1      // 1: the GELU-epilogue launches (fc1 forward, fc2 data gradient: 3072-wide outputs, two to five
                              // stashed tensors per output tile) run on k_gemm_pipe too.  Per-launch it looks slower -- with one block
@@ -596,11 +617,12 @@ template <int N_> DEVI void wait_vm() {
 }
 DEVI void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-template <int ACT>
+template <int ACT_>
 __global__ __launch_bounds__(512, 1) void k_gemm_pipe(const KArgs p) {
   typedef bf16 AT;
+  constexpr int ACT = ACT_ == 1 ? (MDD_PIPE_FAST_GELU ? 2 : 1) : 0;
   constexpr int TM = 4, TN = 2, MODE = 0, CE = 8, BM = 256;
-  constexpr bool IBK = false;
+  constexpr bool IBK = false, EPI_WAVE_SYNC = MDD_PIPE_EPI_WAVE_SYNC != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const ConvGeom& G = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
@@ -747,7 +769,7 @@ bool launch_pipe_gemm(const KArgs& a, hipStream_t st) {
   KArgs k = a;
   k.mtiles = (a.M + 255) / 256;
   k.ntiles = (g.nc + 255) / 256;
-  k.dbg = 0;
+  // (k.dbg: the timing-only switches of debug builds reach this kernel through the common epilogue)
   static std::atomic<uint64_t> attr_devs{0};
   int dev = 0;
   (void)hipGetDevice(&dev);

