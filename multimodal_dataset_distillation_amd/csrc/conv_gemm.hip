@@ -39,6 +39,12 @@
 #define MDD_MIN_WAVES 3
 #endif
 
+#ifndef MDD_PIPE_EPI_HOIST
+#define MDD_PIPE_EPI_HOIST 1  // k_gemm_pipe: first group of stash loads of a 32-row block issued before its LDS transposition
+#endif
+#ifndef MDD_EPI_WAVE_SYNC
+#define MDD_EPI_WAVE_SYNC 0   // k_conv_gemm: wave-level ordering instead of block barriers between the 32-row blocks of the epilogue
+#endif
 #ifndef MDD_SPLIT_3TERM
 #define MDD_SPLIT_3TERM 1   // bf16x2 K loop of the 2x2-wave instances: hh + hl + lh on register-regrouped chunk pairs
                             // (0: hh + ll + hl + lh everywhere)
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
   constexpr int RA = BM / 32, RB = BN / 32;
   typedef typename MmaSel<AT, PREC>::type MT;
   constexpr int KE = MT::KE, CE = MT::CE;
-  constexpr bool EPI_WAVE_SYNC = false;
+  constexpr bool EPI_WAVE_SYNC = MDD_EPI_WAVE_SYNC != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NBUF = MDD_SINGLE_BUF ? 1 : 2;   // LDS stages (registers hold the slab in flight)
 
@@ -583,7 +589,9 @@ __global__ __launch_bounds__(256, MDD_MIN_WAVES) void k_conv_gemm(const KArgs p)
     __syncthreads();
   }
 
+#define MDD_EPI_HOISTED 0
 #include "conv_gemm_epilogue.inc"
+#undef MDD_EPI_HOISTED
 }
 
 
@@ -754,7 +762,9 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pipe(const KArgs p) {
   }
   if (wm == 0) raw_barrier();
   __syncthreads();
+#define MDD_EPI_HOISTED MDD_PIPE_EPI_HOIST
 #include "conv_gemm_epilogue.inc"
+#undef MDD_EPI_HOISTED
 }
 
 // false = shape not taken (the caller goes on to the one-stage kernel)
