@@ -540,7 +540,7 @@ def main():
         torch.cuda.empty_cache()
         others = {}
         for name, extra in (("c4", ["--keep-steps", "0", "--steps", "1", "--warmup", "1", "--expert-source", "host"]),
-                            ("c5", ["--steps", "2", "--warmup", "1"])):
+                            ("c5", ["--steps", "4", "--warmup", "1"])):
             cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--no-cpu-baseline", "--no-roofline",
                    "--no-other-workloads"] + extra
             t1 = time.time()
