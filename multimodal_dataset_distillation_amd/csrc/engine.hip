@@ -363,7 +363,7 @@ struct Eng : mdd_engine {
       stem[0] = stem[1] = stem[2] = stem[3] = fin = -1;
       for (auto& L : convs) {
         LinPackDesc d; d.off_w = L.off_w; d.off_p = L.off_p; d.out = L.cout; d.in = L.cin; d.tile_start = lpd_tiles; d.pad_ = 0;
-        lpd_tiles += ((L.cin + 31) / 32) * ((L.cout + 31) / 32);
+        lpd_tiles += ((L.cin + 63) / 64) * ((L.cout + 63) / 64);      // k_lin_pack_all: 64 x 64 tiles
         lpd.push_back(d);
       }
     } else {

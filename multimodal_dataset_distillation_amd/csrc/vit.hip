@@ -844,34 +844,60 @@ template <class AT> void launch_lin_pack(AT* wf, AT* wt, const float* w, int out
 // every linear of the network (and, with theta_t, its tangent) in ONE launch: block -> (layer, 32x32 tile) by the
 // layers' tile prefix sums
 template <class AT>
-__global__ void k_lin_pack_all(const LinPackDesc* __restrict__ descs, int nd, const float* __restrict__ th,
-                               const float* __restrict__ th_t, AT* __restrict__ wf, AT* __restrict__ wt,
-                               AT* __restrict__ wf_t, AT* __restrict__ wt_t) {
-  __shared__ float tile[2][32][33];
-  int li = 0;
-  while (li + 1 < nd && (int)blockIdx.x >= descs[li + 1].tile_start) ++li;
-  const LinPackDesc d = descs[li];
-  const int t = blockIdx.x - d.tile_start, tpr = (d.in + 31) / 32;
-  const int i0 = (t % tpr) * 32, o0 = (t / tpr) * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+__global__ __launch_bounds__(256) void k_lin_pack_all(const LinPackDesc* __restrict__ descs, int nd, const float* __restrict__ th,
+                                                      const float* __restrict__ th_t, AT* __restrict__ wf, AT* __restrict__ wt,
+                                                      AT* __restrict__ wf_t, AT* __restrict__ wt_t) {
+  // 64 x 64 tiles; a thread moves PAIRS of consecutive elements (8-byte loads, 4- or 8-byte stores: full 128 / 256-byte
+  // rows per wave); the layer of a block by bisection of the tile prefix sums (a linear scan was ~50 dependent loads)
+  __shared__ float tile[2][64][65];
+  int lo = 0, hi = nd - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)blockIdx.x >= descs[mid].tile_start) lo = mid; else hi = mid - 1;
+  }
+  const LinPackDesc d = descs[lo];
+  const int t = blockIdx.x - d.tile_start, tpr = (d.in + 63) / 64;
+  const int i0 = (t % tpr) * 64, o0 = (t / tpr) * 64;
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const float* w = th + d.off_w; const float* w_t = th_t ? th_t + d.off_w : nullptr;
-  for (int r = ty; r < 32; r += 8) {
-    const int o = o0 + r, i = i0 + tx;
-    float v = 0.f, vt = 0.f;
+  const bool even_in = (d.in & 1) == 0, even_out = (d.out & 1) == 0;
+  auto put2 = [](AT* p, float a, float b, bool two, bool aligned) __attribute__((always_inline)) {
+    if constexpr (sizeof(AT) == 2) {
+      if (two && aligned) { *(unsigned*)p = Chunk<bf16>::pk(a, b); return; }
+    } else {
+      if (two && aligned) { *(float2*)p = make_float2(a, b); return; }
+    }
+    p[0] = from_f<AT>(a);
+    if (two) p[1] = from_f<AT>(b);
+  };
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int r = ry + 8 * k, o = o0 + r, i = i0 + 2 * cx;
+    float v0 = 0.f, v1 = 0.f, u0 = 0.f, u1 = 0.f;
     if (o < d.out && i < d.in) {
       const int64_t idx = (int64_t)o * d.in + i;
-      v = w[idx]; wf[d.off_p + idx] = from_f<AT>(v);
-      if (w_t) { vt = w_t[idx]; wf_t[d.off_p + idx] = from_f<AT>(vt); }
+      const bool two = i + 1 < d.in, al = even_in && ((d.off_w & 1) == 0) && ((d.off_p & 1) == 0);
+      if (two && al) { const float2 q = *(const float2*)(w + idx); v0 = q.x; v1 = q.y; }
+      else { v0 = w[idx]; if (two) v1 = w[idx + 1]; }
+      put2(wf + d.off_p + idx, v0, v1, two, al);
+      if (w_t) {
+        if (two && al) { const float2 q = *(const float2*)(w_t + idx); u0 = q.x; u1 = q.y; }
+        else { u0 = w_t[idx]; if (two) u1 = w_t[idx + 1]; }
+        put2(wf_t + d.off_p + idx, u0, u1, two, al);
+      }
     }
-    tile[0][r][tx] = v; tile[1][r][tx] = vt;
+    tile[0][r][2 * cx] = v0; tile[0][r][2 * cx + 1] = v1;
+    tile[1][r][2 * cx] = u0; tile[1][r][2 * cx + 1] = u1;
   }
   __syncthreads();
-  for (int r = ty; r < 32; r += 8) {
-    const int i = i0 + r, o = o0 + tx;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int r = ry + 8 * k, i = i0 + r, o = o0 + 2 * cx;
     if (o < d.out && i < d.in) {
       const int64_t idx = (int64_t)i * d.out + o;
-      wt[d.off_p + idx] = from_f<AT>(tile[0][tx][r]);
-      if (w_t) wt_t[d.off_p + idx] = from_f<AT>(tile[1][tx][r]);
+      const bool two = o + 1 < d.out, al = even_out && ((d.off_p & 1) == 0);
+      put2(wt + d.off_p + idx, tile[0][2 * cx][r], tile[0][2 * cx + 1][r], two, al);
+      if (w_t) put2(wt_t + d.off_p + idx, tile[1][2 * cx][r], tile[1][2 * cx + 1][r], two, al);
     }
   }
 }
