@@ -26,6 +26,7 @@
 #include <cstdint>
 #include <type_traits>
 #include <cstdlib>
+#include <cstring>
 
 #include "kernels.h"
 
@@ -517,10 +518,22 @@ template <int N_> DEVI void wait_vm() {
 DEVI void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
 constexpr int WGP_NS = MDD_WGP_SLOTS, WGP_D = WGP_NS - 2;   // ring slots, issue distance in phases (see "Hazards")
-__global__ __launch_bounds__(512, 1) void k_wgrad_pipe(const WArgs p) {
+// one to four layers with the same pixel count in one launch (a ViT layer's four linears: 108 tiles instead of 9-36,
+// two or three pixel chunks instead of seven -- a third of the partial-tile traffic)
+struct WProb {
+  const void *dy1, *x1, *dy2, *x2;
+  float* dW; float* dbias;
+  int64_t slab_off;            // floats, inside one split's slab
+  int nc, kc, co_tot, ca_tot, kptiles, tile_start;
+};
+struct WGroup {
+  WProb pr[4];
+  int n, M, mchunk, tiles;
+  float* slab; int64_t slab_stride;
+};
+__global__ __launch_bounds__(512, 1) void k_wgrad_pipe(const WGroup pg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NS = WGP_NS, D = WGP_D;
-  const ConvGeom& G = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wc = wave >> 2, wk = wave & 3;
   int bid, bsplit;
   {
@@ -530,14 +543,18 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_pipe(const WArgs p) {
     bsplit = lin / gridDim.x;
     bid = lin - bsplit * gridDim.x;
   }
-  const int kpt = bid % p.kptiles, cot = bid / p.kptiles;
+  int pi = 0;
+  while (pi + 1 < pg.n && bid >= pg.pr[pi + 1].tile_start) ++pi;
+  const WProb& q_ = pg.pr[pi];
+  bid -= q_.tile_start;
+  const int kpt = bid % q_.kptiles, cot = bid / q_.kptiles;
   const int co0 = cot * 256, kp0 = kpt * 256;
-  const int ktot = G.kc;
-  const int mbeg = bsplit * p.mchunk;
-  const int mend = min(p.M, mbeg + p.mchunk);
+  const int ktot = q_.kc;
+  const int mbeg = bsplit * pg.mchunk;
+  const int mend = min(pg.M, mbeg + pg.mchunk);
   const int rows = mend - mbeg;
   const int nk1 = (rows + 63) >> 6;
-  const int nk = p.dy2 ? 2 * nk1 : nk1;
+  const int nk = q_.dy2 ? 2 * nk1 : nk1;
   const int H = 4 * nk;
 
   // ---- loader: two 1-KB wave instructions per half-tile; instruction j covers pixel rows j*32 + wave*4 + (lane>>4),
@@ -547,14 +564,14 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_pipe(const WArgs p) {
   const int lcidx = (lane & 15) ^ ((lrow0 & 7) << 1);
   const int dch0 = co0 + lcidx * 8;       // channel of half 0; half 1 is + 128: every half-tile row is ONE 256-byte segment
   const int xkk0 = kp0 + lcidx * 8;
-  const unsigned dv0 = (unsigned)((lrow0 * G.co_tot + dch0) * 2), xv0 = (unsigned)((lrow0 * G.ca_tot + xkk0) * 2);
-  const unsigned drow32 = (unsigned)(32 * G.co_tot * 2), xrow32 = (unsigned)(32 * G.ca_tot * 2);
+  const unsigned dv0 = (unsigned)((lrow0 * q_.co_tot + dch0) * 2), xv0 = (unsigned)((lrow0 * q_.ca_tot + xkk0) * 2);
+  const unsigned drow32 = (unsigned)(32 * q_.co_tot * 2), xrow32 = (unsigned)(32 * q_.ca_tot * 2);
   const char* const zsrc = (const char*)g_wzero + (lane & 15) * 16;
-  const size_t dstep = (size_t)64 * G.co_tot * 2, xstep = (size_t)64 * G.ca_tot * 2;
-  const char* const dy1b = (const char*)p.dy1 + (size_t)mbeg * G.co_tot * 2;
-  const char* const x1b = (const char*)p.x1 + (size_t)mbeg * G.ca_tot * 2;
-  const char* const dy2b = (const char*)(p.dy2 ? p.dy2 : p.dy1) + (size_t)mbeg * G.co_tot * 2;
-  const char* const x2b = (const char*)(p.x2 ? p.x2 : p.x1) + (size_t)mbeg * G.ca_tot * 2;
+  const size_t dstep = (size_t)64 * q_.co_tot * 2, xstep = (size_t)64 * q_.ca_tot * 2;
+  const char* const dy1b = (const char*)q_.dy1 + (size_t)mbeg * q_.co_tot * 2;
+  const char* const x1b = (const char*)q_.x1 + (size_t)mbeg * q_.ca_tot * 2;
+  const char* const dy2b = (const char*)(q_.dy2 ? q_.dy2 : q_.dy1) + (size_t)mbeg * q_.co_tot * 2;
+  const char* const x2b = (const char*)(q_.x2 ? q_.x2 : q_.x1) + (size_t)mbeg * q_.ca_tot * 2;
   typedef const void __attribute__((address_space(1)))* gptr_t;
   typedef void __attribute__((address_space(3)))* lptr_t;
   // half-tile hh = 4*kt + {0: D0, 1: X0, 2: X1, 3: D1} -> ring slot hh % NS (the caller passes it)
@@ -568,7 +585,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_pipe(const WArgs p) {
     const int rem = rows - ktl * 64;
     if constexpr (MDD_WGP_ABL & 2) return;
     char* dst = smem + slot * 16384 + wave * 1024;
-    const bool colok = isd ? (dch0 + 128 * h) < G.nc : (xkk0 + 128 * h) < ktot;
+    const bool colok = isd ? (dch0 + 128 * h) < q_.nc : (xkk0 + 128 * h) < ktot;
     const unsigned vo = (isd ? dv0 : xv0) + 256u * h;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -603,7 +620,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_pipe(const WArgs p) {
 
   // bias gradient (column sums of dy1) from the D half-tiles in LDS, by the blocks of k'-tile 0: thread t adds the
   // chunks (row t>>4 + 32u, slot t&15) -- one fixed 8-channel chunk of the half-tile per thread
-  const bool do_bias = p.dbias != nullptr && kpt == 0;
+  const bool do_bias = q_.dbias != nullptr && kpt == 0;
   float bsum[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
@@ -731,15 +748,15 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_pipe(const WArgs p) {
   __syncthreads();
 
   // ---- write-out: rows = k' (4 consecutive per lane), columns = co, as the one-stage kernel
-  float* dst = p.slab ? p.slab + (size_t)bsplit * p.slab_stride : p.dW;
-  const bool plain = p.slab != nullptr;
+  float* dst = pg.slab ? pg.slab + (size_t)bsplit * pg.slab_stride + q_.slab_off : q_.dW;
+  const bool plain = pg.slab != nullptr;
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if constexpr (MDD_WGP_ABL & 8) { asm volatile("" :: "v"(acc[i][j])); continue; }
       const int co = co0 + (i >> 2) * 128 + wc * 64 + 16 * (i & 3) + li, kcol = kp0 + (j >> 1) * 128 + wk * 32 + 16 * (j & 1) + 4 * gq;
-      if (co >= G.nc || kcol >= ktot) continue;
+      if (co >= q_.nc || kcol >= ktot) continue;
       float* a = dst + (size_t)co * ktot + kcol;
       if (plain) {
         *(float4*)a = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
@@ -758,7 +775,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_pipe(const WArgs p) {
       float s = 0.f;
       for (int r = 0; r < 16; ++r) s += sh[(h * 16 + r) * 128 + col];
       const int ch = co0 + h * 128 + col;
-      if (ch < G.nc) atomicAdd(p.dbias + ch, s);
+      if (ch < q_.nc) atomicAdd(q_.dbias + ch, s);
     }
   }
 }
@@ -1019,41 +1036,86 @@ bool launch_slab(WArgs a, float* slab, int64_t slab_floats, hipEvent_t ev_mid, h
   return true;
 }
 
-// split policy and launch of k_wgrad_pipe; false = shape not taken (the caller falls through to the one-stage kernel)
-bool launch_pipe(WArgs a, float* slab, int64_t slab_floats, hipEvent_t ev_mid, hipStream_t st) {
-  const ConvGeom& g = a.g;
+// sum of the split slabs of up to four layers in one launch: segment i covers float4 columns [start4[i], start4[i+1])
+struct WRed { float* dW[4]; int64_t start4[5]; int n; };
+__global__ __launch_bounds__(256) void k_wgrad_reduce_group(const WRed r, const float* __restrict__ slab, int64_t stride4,
+                                                              int splits) {
+  __shared__ float4 part[16][17];
+  const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int64_t i = (int64_t)blockIdx.x * 16 + col;
+  const int64_t n4 = r.start4[r.n];
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    const float4* src = (const float4*)slab + i;
+    for (int k = sl; k < splits; k += 16) {
+      const float4 v = src[(int64_t)k * stride4];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  part[sl][col] = s;
+  __syncthreads();
+  if (sl == 0 && i < n4) {
+    float4 t = part[0][col];
+#pragma unroll
+    for (int l = 1; l < 16; ++l) { float4 v = part[l][col]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    int seg = 0;
+    while (seg + 1 < r.n && i >= r.start4[seg + 1]) ++seg;
+    ((float4*)r.dW[seg])[i - r.start4[seg]] = t;
+  }
+}
+
+bool pipe_wgrad_takes(const ConvGeom& g, int M) {
   const bool pw = g.k == 1 && g.stride == 1 && g.pad == 0 && g.groups == 1;
-  if (!pipe_kernels_enabled() || !pw || g.nc < MDD_WG_PIPE_MIN || g.kc < MDD_WG_PIPE_MIN || (g.kc & 7) || (g.nc & 7) || (g.co_tot & 7) || (g.ca_tot & 7) ||
-      a.M < 8192)
-    return false;
-  const int ktot = g.kc;
-  a.cotiles = (g.nc + 255) / 256;
-  a.kptiles = (ktot + 255) / 256;
-  const int tiles = a.cotiles * a.kptiles;
-  const int nsrc = a.dy2 ? 2 : 1;
-  const int64_t out_floats = (int64_t)g.nc * ktot;
+  return pipe_kernels_enabled() && pw && g.prec == 0 && g.nc >= MDD_WG_PIPE_MIN && g.kc >= MDD_WG_PIPE_MIN && !(g.kc & 7) && !(g.nc & 7) &&
+         !(g.co_tot & 7) && !(g.ca_tot & 7) && M >= 8192;
+}
+
+// split policy and launch of k_wgrad_pipe for one to four layers that share the pixel count and the pairing (all with or
+// all without a second operand pair); false = not taken (the caller falls through to the one-stage kernel, one layer at
+// a time)
+struct WItem { ConvGeom g; const void *dy1, *x1, *dy2, *x2; float* dW; float* dbias; };
+bool launch_pipe_group(const WItem* it, int n, int M, float* slab, int64_t slab_floats, hipEvent_t ev_mid, hipStream_t st) {
+  if (n < 1 || n > 4) return false;
+  WGroup G;
+  memset(&G, 0, sizeof G);
+  int tiles = 0;
+  int64_t out_floats = 0;
+  bool aligned = true;
+  for (int i = 0; i < n; ++i) {
+    const ConvGeom& g = it[i].g;
+    if (!pipe_wgrad_takes(g, M) || (it[i].dy2 != nullptr) != (it[0].dy2 != nullptr)) return false;
+    WProb& q = G.pr[i];
+    q.dy1 = it[i].dy1; q.x1 = it[i].x1; q.dy2 = it[i].dy2; q.x2 = it[i].x2; q.dW = it[i].dW; q.dbias = it[i].dbias;
+    q.nc = g.nc; q.kc = g.kc; q.co_tot = g.co_tot; q.ca_tot = g.ca_tot;
+    q.kptiles = (g.kc + 255) / 256;
+    q.tile_start = tiles;
+    q.slab_off = out_floats;
+    tiles += ((g.nc + 255) / 256) * q.kptiles;
+    const int64_t of = (int64_t)g.nc * g.kc;
+    aligned = aligned && of % 4 == 0 && ((uintptr_t)it[i].dW & 15) == 0;
+    out_floats += of;
+  }
+  const int nsrc = it[0].dy2 ? 2 : 1;
   const double out_mb = (double)out_floats * 4.0 / 1e6;
-  const bool two_phase = slab != nullptr && slab_floats >= out_floats && out_floats % 4 == 0 && ((uintptr_t)a.dW & 15) == 0;
+  const bool two_phase = slab != nullptr && slab_floats >= out_floats && aligned;
   const double comb_us_per_mb = two_phase ? 0.6 : 1.0 / 1.3;
-  int maxsplits = a.M / 256;     // at least four K-tiles per block
+  int maxsplits = M / 256;     // at least four K-tiles per block
   if (two_phase && maxsplits > slab_floats / out_floats) maxsplits = (int)(slab_floats / out_floats);
   if (maxsplits < 1) maxsplits = 1;
   int splits = 1;
   double best = 1e30;
   for (int sp = 1; sp <= maxsplits; ++sp) {
-    const int chunk = ((a.M + sp - 1) / sp + 63) / 64 * 64;
+    const int chunk = ((M + sp - 1) / sp + 63) / 64 * 64;
     const double steps = (double)nsrc * chunk / 64;
     const double waves = (double)(((int64_t)tiles * sp + 255) / 256);      // one block per CU
     const double t = waves * (steps * 0.9 + 8.0) + out_mb * sp * comb_us_per_mb;
     if (t < best) { best = t; splits = sp; }
   }
-  int mchunk = ((a.M + splits - 1) / splits + 63) / 64 * 64;
-  splits = (a.M + mchunk - 1) / mchunk;
-  if (a.M - (splits - 1) * mchunk < 1) return false;
-  a.mchunk = mchunk;
-  a.dbg = 0;
-  a.slab = two_phase ? slab : nullptr;
-  a.slab_stride = out_floats;
+  int mchunk = ((M + splits - 1) / splits + 63) / 64 * 64;
+  splits = (M + mchunk - 1) / mchunk;
+  G.n = n; G.M = M; G.mchunk = mchunk; G.tiles = tiles;
+  G.slab = two_phase ? slab : nullptr;
+  G.slab_stride = out_floats;
   static std::atomic<uint64_t> attr_devs{0};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -1062,13 +1124,22 @@ bool launch_pipe(WArgs a, float* slab, int64_t slab_floats, hipEvent_t ev_mid, h
     if (hipFuncSetAttribute((const void*)k_wgrad_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, WGP_NS * 16384) != hipSuccess) return false;
     attr_devs.fetch_or(bit, std::memory_order_release);
   }
-  k_wgrad_pipe<<<dim3(tiles, splits), 512, WGP_NS * 16384, st>>>(a);
+  k_wgrad_pipe<<<dim3(tiles, splits), 512, WGP_NS * 16384, st>>>(G);
   if (ev_mid) (void)hipEventRecord(ev_mid, st);
   if (two_phase) {
-    const int64_t n4 = out_floats / 4;
-    k_wgrad_reduce<<<(unsigned)((n4 + 15) / 16), 256, 0, st>>>(a.dW, slab, n4, out_floats / 4, splits);
+    WRed r;
+    memset(&r, 0, sizeof r);
+    r.n = n;
+    for (int i = 0; i < n; ++i) { r.dW[i] = it[i].dW; r.start4[i] = G.pr[i].slab_off / 4; }
+    r.start4[n] = out_floats / 4;
+    k_wgrad_reduce_group<<<(unsigned)((out_floats / 4 + 15) / 16), 256, 0, st>>>(r, slab, out_floats / 4, splits);
   }
   return true;
+}
+bool launch_pipe(WArgs a, float* slab, int64_t slab_floats, hipEvent_t ev_mid, hipStream_t st) {
+  WItem it;
+  it.g = a.g; it.dy1 = a.dy1; it.x1 = a.x1; it.dy2 = a.dy2; it.x2 = a.x2; it.dW = a.dW; it.dbias = a.dbias;
+  return launch_pipe_group(&it, 1, a.M, slab, slab_floats, ev_mid, st);
 }
 
 template <class AT, int BCO, int BKP, int BKM>
@@ -1167,6 +1238,19 @@ void launch_conv_wgrad(const ConvGeom& g, const AT* dy1, const AT* x1, const AT*
   } else {
     launch_cfg<AT, 64, 128, 32>(a, slab, slab_floats, ev_mid, st);
   }
+}
+bool conv_wgrad_group_takes(const ConvGeom& g) { return pipe_wgrad_takes(g, g.nimg * g.ho * g.wo); }
+// several wide pointwise bf16 layers with the same pixel count in ONE launch (a ViT layer's four linears)
+bool launch_conv_wgrad_group(const WgradItem* items, int n, float* slab, int64_t slab_floats, hipStream_t st) {
+  if (n < 1 || n > 4) return false;
+  WItem it[4];
+  const int M = items[0].g.nimg * items[0].g.ho * items[0].g.wo;
+  for (int i = 0; i < n; ++i) {
+    if (items[i].g.nimg * items[i].g.ho * items[i].g.wo != M) return false;
+    it[i].g = items[i].g; it[i].dy1 = items[i].dy1; it[i].x1 = items[i].x1; it[i].dy2 = items[i].dy2; it[i].x2 = items[i].x2;
+    it[i].dW = items[i].dW; it[i].dbias = items[i].dbias;
+  }
+  return launch_pipe_group(it, n, M, slab, slab_floats, nullptr, st);
 }
 template void launch_conv_wgrad<float>(const ConvGeom&, const float*, const float*, const float*,
                                        const float*, float*, float*, float*, int64_t, hipEvent_t, hipStream_t);

@@ -864,6 +864,9 @@ struct Eng : mdd_engine {
   // barrier packet on the main queue (~8-12 us bubble each), and nothing on the main stream waits for
   // these results before the end of the pass.
   static constexpr bool MAIN_TAIL = true;
+#ifndef MDD_WGRAD_GROUP
+#define MDD_WGRAD_GROUP 1        // the wide pointwise layers queued between two flushes share one weight-gradient launch
+#endif
 #ifndef MDD_FLUSH_EVERY
 #define MDD_FLUSH_EVERY 1        // release queued weight gradients to the side stream every this many blocks
 #endif
@@ -874,22 +877,54 @@ struct Eng : mdd_engine {
 #define MDD_FWD_SHORTCUT_SIDE 1  // forward passes: shortcut branch (avg-pool + 1x1 conv) on the side stream
 #endif
   std::vector<std::function<void(hipStream_t)>> wq;
+  // wide pointwise layers (the ViT linears) queued since the last flush: launched together, up to four per launch
+  // (csrc/conv_wgrad.hip launch_conv_wgrad_group: a layer's 108 tiles need two pixel chunks instead of seven)
+  struct WgQ { const ConvL* L; WgradItem it; };
+  std::vector<WgQ> wgroup;
+  void flush_group(hipStream_t ws_) {
+    size_t i = 0;
+    while (i < wgroup.size()) {
+      size_t j = i + 1;
+      while (j < wgroup.size() && j - i < 4 && (wgroup[j].it.dy2 != nullptr) == (wgroup[i].it.dy2 != nullptr)) ++j;
+      WgradItem items[4];
+      for (size_t k = i; k < j; ++k) items[k - i] = wgroup[k].it;
+      float* slab = (use_side && ws_ == side) ? wslab[1] : wslab[0];
+      if (j - i < 2 || !launch_conv_wgrad_group(items, (int)(j - i), slab, wslab_floats, ws_)) {
+        for (size_t k = i; k < j; ++k) {
+          const WgradItem& w = wgroup[k].it;
+          wgrad(*wgroup[k].L, w.g, (const AT*)w.dy1, (const AT*)w.x1, (const AT*)w.dy2, (const AT*)w.x2, w.dW, w.dbias, ws_);
+        }
+      }
+      i = j;
+    }
+    wgroup.clear();
+  }
   void flush_w(hipStream_t st, bool on_main = false) {
-    if (wq.empty()) return;
+    if (wq.empty() && wgroup.empty()) return;
     if (on_main) {   // tail of the pass: the side stream is the one lagging, the main stream helps out
       for (auto& f : wq) f(st);
       wq.clear();
+      flush_group(st);
       return;
     }
     fork(st);
     hipStream_t ws_ = wstream(st);
     for (auto& f : wq) f(ws_);
     wq.clear();
+    flush_group(ws_);
   }
   // weight + bias gradient of conv L (dy = grad wrt its raw output, x = its input)
   void conv_bwd_w(bool T, const ConvL& L, const AT* dy, const AT* dy_t, const AT* x, const AT* x_t,
                   float* dwf_, float* dwf_t_, float* gout, hipStream_t) {
     const ConvL* Lp = &L;
+    if (sizeof(AT) == 2 && MDD_WGRAD_GROUP && !prof_on && conv_wgrad_group_takes(gfwd(L))) {
+      WgQ q; q.L = Lp; q.it.g = gfwd(L);
+      if (!T) { q.it.dy1 = dy; q.it.x1 = x; q.it.dy2 = nullptr; q.it.x2 = nullptr; q.it.dW = dwf_ + L.off_p; }
+      else { q.it.dy1 = dy_t; q.it.x1 = x; q.it.dy2 = x_t ? dy : nullptr; q.it.x2 = x_t; q.it.dW = dwf_t_ + L.off_p; }
+      q.it.dbias = gout + L.off_b;
+      wgroup.push_back(q);
+      return;
+    }
     wq.push_back([=](hipStream_t ws_) {
       ConvGeom g = gfwd(*Lp);
       if (!T) wgrad(*Lp, g, dy, x, nullptr, nullptr, dwf_ + Lp->off_p, gout + Lp->off_b, ws_);

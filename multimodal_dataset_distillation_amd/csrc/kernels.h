@@ -109,6 +109,11 @@ template <class AT>
 void launch_conv_wgrad(const ConvGeom& g, const AT* dy1, const AT* x1, const AT* dy2, const AT* x2,
                        float* dW, float* dbias, float* slab, int64_t slab_floats, hipEvent_t ev_mid,
                        hipStream_t st);
+// one launch for up to four wide pointwise bf16 layers that share the pixel count and the pairing (a ViT layer's four
+// linears); false = not taken, launch them one by one
+struct WgradItem { ConvGeom g; const void *dy1, *x1, *dy2, *x2; float* dW; float* dbias; };
+bool launch_conv_wgrad_group(const WgradItem* items, int n, float* slab, int64_t slab_floats, hipStream_t st);
+bool conv_wgrad_group_takes(const ConvGeom& g);   // such a layer (bf16 storage)
 
 // ---------------------------------------------------------------- elementwise.hip
 template <class AT>
