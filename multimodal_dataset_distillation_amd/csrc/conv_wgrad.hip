@@ -645,36 +645,43 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_pipe(const WGroup pg) {
   // wait statements below, which name every destination register so that no consumer is scheduled above them.
   const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
   s16x4 af[2][2][4], b0[2][2][2], b1[2][2][2];
-  auto tr0 = [](unsigned a) __attribute__((always_inline)) {
+  // fragment addresses inside slot 0, one register per (e, block): a read then costs no vector-ALU instruction -- the slot
+  // (compile-time inside the K loop, unrolled by two K-tiles = the eight ring slots) and the second 32-pixel step go into
+  // the instruction's 16-bit offset, slots 4..7 through + 65536 on the registers once per K-tile.  With the address
+  // arithmetic per read, phase 0 of a wave row (24 reads) outlasted the other row's 16 MFMAs.
+  unsigned aD[2][4], aX[2][2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aD[e][i] = (lds0 + rdD0[e]) ^ (unsigned)(32 * i);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) aX[e][j] = (lds0 + rdX0[e]) ^ (unsigned)(32 * j);
+  }
+  auto trd = [](unsigned a, auto OFF) __attribute__((always_inline)) {
     s16x4 v;
     if constexpr (MDD_WGP_ABL & 4) asm volatile("" : "=v"(v) : "v"(a)); else
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(a));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(a), "i"(decltype(OFF)::value));
     return v;
   };
-  auto tr1 = [](unsigned a) __attribute__((always_inline)) {
-    s16x4 v;
-    if constexpr (MDD_WGP_ABL & 4) asm volatile("" : "=v"(v) : "v"(a)); else
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(v) : "v"(a));
-    return v;
-  };
-  auto read_d = [&](unsigned slot) __attribute__((always_inline)) {
+  // SL: slot inside the half of the ring (0..3); hi: 0 or 65536 (slots 4..7)
+  auto read_d = [&](auto SL, unsigned hi) __attribute__((always_inline)) {
+    constexpr int o = decltype(SL)::value * 16384;
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const unsigned a = (slot + rdD0[e]) ^ (unsigned)(32 * i);
-        af[0][e][i] = tr0(a);
-        af[1][e][i] = tr1(a);
+        af[0][e][i] = trd(aD[e][i] + hi, std::integral_constant<int, o>{});
+        af[1][e][i] = trd(aD[e][i] + hi, std::integral_constant<int, o + 8192>{});
       }
   };
-  auto read_x = [&](unsigned slot, s16x4 (&b)[2][2][2]) __attribute__((always_inline)) {
+  auto read_x = [&](auto SL, unsigned hi, s16x4 (&b)[2][2][2]) __attribute__((always_inline)) {
+    constexpr int o = decltype(SL)::value * 16384;
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const unsigned a = (slot + rdX0[e]) ^ (unsigned)(32 * j);
-        b[0][e][j] = tr0(a);
-        b[1][e][j] = tr1(a);
+        b[0][e][j] = trd(aX[e][j] + hi, std::integral_constant<int, o>{});
+        b[1][e][j] = trd(aX[e][j] + hi, std::integral_constant<int, o + 8192>{});
       }
   };
 #define MDD_B8(b) "+v"(b[0][0][0]), "+v"(b[0][0][1]), "+v"(b[0][1][0]), "+v"(b[0][1][1]), "+v"(b[1][0][0]), "+v"(b[1][0][1]), \
@@ -703,44 +710,50 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_pipe(const WGroup pg) {
   for (int hh = 0; hh < D; ++hh)
     if (hh < H) issue(hh, hh);
   if (H >= D + 2) wait_vm<2 * (D - 2)>(); else wait_vm<0>();    // D0, X0 of K-tile 0 have landed (this wave's share)
-  int sb = 0;                                     // ring slot of this K-tile's first half-tile = (4 kt) % NS
-  auto slot_of = [](int s) __attribute__((always_inline)) { return s >= 2 * NS ? s - 2 * NS : (s >= NS ? s - NS : s); };
   raw_barrier();
   if (wc == 1) raw_barrier();
-  for (int kt = 0; kt < nk; ++kt) {
+  static_assert(NS == 8 && D == 6, "the K loop below is unrolled over the eight ring slots");
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  // one K-tile whose half-tiles sit in slots 4 PAR .. 4 PAR + 3 (PAR = kt & 1)
+  auto ktile = [&](const int kt, auto PARc) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(PARc)::value;
+    const unsigned hi = PAR ? 65536u : 0u;
     const int g0 = 4 * kt;
-    const int o0 = slot_of(sb) * 16384, o1 = slot_of(sb + 1) * 16384, o2 = slot_of(sb + 2) * 16384, o3 = slot_of(sb + 3) * 16384;
     const bool bias_now = do_bias && kt < nk1;
     // ---- phase 0: D0, X0 ; quadrant (0, 0)
-    if (bias_now && wc == 0) bias_add(lds0 + o0);
-    read_x(lds0 + o1, b0);
-    read_d(lds0 + o0);
-    if (g0 + D < H) { issue(g0 + D, slot_of(sb + D)); wait_vm<2 * (D - 2)>(); } else wait_vm<0>();
+    if (bias_now && wc == 0) bias_add(lds0 + (4 * PAR + 0) * 16384);
+    read_x(I1{}, hi, b0);
+    read_d(I0{}, hi);
+    if (g0 + 6 < H) { issue(g0 + 6, (4 * PAR + 6) & 7); wait_vm<8>(); } else wait_vm<0>();
     raw_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" : MDD_B8(b0), MDD_A16);
     quad(b0, 0, 0);
     raw_barrier();
     // ---- phase 1: X1 ; quadrant (0, 1)
-    read_x(lds0 + o2, b1);
-    if (g0 + D + 1 < H) { issue(g0 + D + 1, slot_of(sb + D + 1)); wait_vm<2 * (D - 2)>(); } else wait_vm<0>();
+    read_x(I2{}, hi, b1);
+    if (g0 + 7 < H) { issue(g0 + 7, (4 * PAR + 7) & 7); wait_vm<8>(); } else wait_vm<0>();
     raw_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" : MDD_B8(b1));
     quad(b1, 0, 2);
     raw_barrier();
     // ---- phase 2: D1 ; quadrant (1, 1)
-    if (bias_now && wc == 1) bias_add(lds0 + o3);
-    read_d(lds0 + o3);
-    if (g0 + D + 2 < H) { issue(g0 + D + 2, slot_of(sb + D + 2)); wait_vm<2 * (D - 1)>(); } else wait_vm<0>();
+    if (bias_now && wc == 1) bias_add(lds0 + (4 * PAR + 3) * 16384);
+    read_d(I3{}, hi);
+    if (g0 + 8 < H) { issue(g0 + 8, (4 * PAR + 8) & 7); wait_vm<10>(); } else wait_vm<0>();
     raw_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" : MDD_A16);
     quad(b1, 4, 2);
     raw_barrier();
     // ---- phase 3: nothing new ; quadrant (1, 0)
-    if (g0 + D + 3 < H) { issue(g0 + D + 3, slot_of(sb + D + 3)); wait_vm<2 * (D - 2)>(); } else wait_vm<0>();
+    if (g0 + 9 < H) { issue(g0 + 9, (4 * PAR + 9) & 7); wait_vm<8>(); } else wait_vm<0>();
     raw_barrier();
     quad(b0, 4, 0);
     raw_barrier();
-    sb = slot_of(sb + 4);
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    ktile(kt, I0{});
+    if (kt + 1 < nk) ktile(kt + 1, I1{});
   }
 #undef MDD_B8
 #undef MDD_A16
