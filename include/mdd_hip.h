@@ -288,6 +288,11 @@ int mdd_op_attention(int mode, int n, int tokens, int heads, float scale, const 
                      float* r, float* D, float* D_t, int r_tan, int accum, int skip0, void* stream);
 int mdd_op_layernorm(int dtype, int rows, int dim, float eps, const void* x, const void* x_t, const float* gamma,
                      const float* gamma_t, const float* beta, const float* beta_t, void* y, void* y_t, void* stream);
+/* LayerNorm of a residual sum in one pass: s = a + b (stored in the storage type, normalised as stored), y = LN(s).
+ * Tangent call (gamma_t given): s is the stashed primal sum (read), s_t = a_t + b_t (stored), y_t the tangent. */
+int mdd_op_add_layernorm(int dtype, int rows, int dim, float eps, const void* a, const void* a_t, const void* b,
+                         const void* b_t, void* s, void* s_t, const float* gamma, const float* gamma_t, const float* beta,
+                         const float* beta_t, void* y, void* y_t, void* stream);
 int mdd_op_layernorm_bwd(int dtype, int rows, int dim, float eps, const void* x, const void* x_t, const void* dy,
                          const void* dy_t, const float* gamma, const float* gamma_t, const void* res,
                          const void* res_t, void* dx, void* dx_t, float* dgamma, float* dgamma_t, float* dbeta,

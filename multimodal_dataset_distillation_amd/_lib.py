@@ -78,6 +78,7 @@ SIGNATURES = {
     "mdd_comm_world": (_I, [_P]),
     "mdd_allreduce_syn_grads": (_I, [_P, _P, _L, _I, _P]),
     "mdd_op_layernorm": (_I, [_I, _I, _I, _F] + [_P] * 9),
+    "mdd_op_add_layernorm": (_I, [_I, _I, _I, _F] + [_P] * 13),
     "mdd_op_layernorm_bwd": (_I, [_I, _I, _I, _F] + [_P] * 15),
     "mdd_op_gelu": (_I, [_I, _L] + [_P] * 5),
     "mdd_op_gelu_bwd": (_I, [_I, _L] + [_P] * 7),

@@ -864,6 +864,9 @@ struct Eng : mdd_engine {
   // barrier packet on the main queue (~8-12 us bubble each), and nothing on the main stream waits for
   // these results before the end of the pass.
   static constexpr bool MAIN_TAIL = true;
+#ifndef MDD_VIT_FUSE_ADD_LN
+#define MDD_VIT_FUSE_ADD_LN 1    // ViT: a residual sum is formed by the LayerNorm kernel that reads it (mdd_op_add_layernorm)
+#endif
 #ifndef MDD_WGRAD_GROUP
 #define MDD_WGRAD_GROUP 1        // the wide pointwise layers queued between two flushes share one weight-gradient launch
 #endif
@@ -1007,8 +1010,16 @@ struct Eng : mdd_engine {
     for (int l = 0; l < vit.depth; ++l) {
       const VitBlkL& B = vblk[l]; VitActs& pa = P.vb[l]; VitActs& qa = Q.vb[l];
       const AT *x = P.X[l], *x_t = T ? Q.X[l] : nullptr;
-      VIT_RC(mdd_op_layernorm(VDT, M, D, vit.eps, x, x_t, th + B.ln1_w, tp(th_t + B.ln1_w), th + B.ln1_b,
-                              tp(th_t + B.ln1_b), pa.N1, T ? qa.N1 : nullptr, st));
+      if (MDD_VIT_FUSE_ADD_LN && l > 0) {
+        // x_l = x2_{l-1} + fc2 output (still in TMP) is formed by the kernel that normalises it
+        VitActs& pp = P.vb[l - 1]; VitActs& qp = Q.vb[l - 1];
+        VIT_RC(mdd_op_add_layernorm(VDT, M, D, vit.eps, pp.X2, T ? qp.X2 : nullptr, P.TMP, T ? Q.TMP : nullptr, P.X[l],
+                                    T ? Q.X[l] : nullptr, th + B.ln1_w, tp(th_t + B.ln1_w), th + B.ln1_b, tp(th_t + B.ln1_b),
+                                    pa.N1, T ? qa.N1 : nullptr, st));
+      } else {
+        VIT_RC(mdd_op_layernorm(VDT, M, D, vit.eps, x, x_t, th + B.ln1_w, tp(th_t + B.ln1_w), th + B.ln1_b,
+                                tp(th_t + B.ln1_b), pa.N1, T ? qa.N1 : nullptr, st));
+      }
       conv_fwd(T, convs[B.qkv], pa.N1, qa.N1, pa.QKV, qa.QKV, nullptr, nullptr, 1.f, th, th_t, st);
       // attention: scores -> probabilities (in place) -> weighted values.  Tangent of the softmax from the stashed
       // probabilities: p_t = scale * p * (s_t - <p, s_t>) -- the softmax Jacobian is symmetric, so it is the
@@ -1031,9 +1042,15 @@ struct Eng : mdd_engine {
         VIT_RC(mdd_op_bgemm(bdt(), 0, 0, &ad.o, pa.P, qa.P, v, v_t, nullptr, qa.O, st));
       }
       conv_fwd(T, convs[B.proj], pa.O, qa.O, P.TMP, Q.TMP, nullptr, nullptr, 1.f, th, th_t, st);
-      launch_add2<AT>(pa.X2, T ? qa.X2 : nullptr, x, x_t, P.TMP, T ? Q.TMP : nullptr, (int64_t)M * D, st);
-      VIT_RC(mdd_op_layernorm(VDT, M, D, vit.eps, pa.X2, T ? qa.X2 : nullptr, th + B.ln2_w, tp(th_t + B.ln2_w),
-                              th + B.ln2_b, tp(th_t + B.ln2_b), pa.N2, T ? qa.N2 : nullptr, st));
+      if (MDD_VIT_FUSE_ADD_LN) {
+        VIT_RC(mdd_op_add_layernorm(VDT, M, D, vit.eps, x, x_t, P.TMP, T ? Q.TMP : nullptr, pa.X2, T ? qa.X2 : nullptr,
+                                    th + B.ln2_w, tp(th_t + B.ln2_w), th + B.ln2_b, tp(th_t + B.ln2_b), pa.N2,
+                                    T ? qa.N2 : nullptr, st));
+      } else {
+        launch_add2<AT>(pa.X2, T ? qa.X2 : nullptr, x, x_t, P.TMP, T ? Q.TMP : nullptr, (int64_t)M * D, st);
+        VIT_RC(mdd_op_layernorm(VDT, M, D, vit.eps, pa.X2, T ? qa.X2 : nullptr, th + B.ln2_w, tp(th_t + B.ln2_w),
+                                th + B.ln2_b, tp(th_t + B.ln2_b), pa.N2, T ? qa.N2 : nullptr, st));
+      }
       // fc1 with the exact GELU in its epilogue (C and A = gelu(C) written by the contraction; tangent: C_t and
       // A_t = gelu'(C) C_t) wherever the GELU instance of the kernel exists for this width
       if (MDD_VIT_FUSE_GELU && conv_gemm_supports_gelu(gfwd(convs[B.fc1]))) {
@@ -1043,8 +1060,9 @@ struct Eng : mdd_engine {
         VIT_RC(mdd_op_gelu(VDT, (int64_t)M * 4 * D, pa.C, T ? qa.C : nullptr, pa.A, T ? qa.A : nullptr, st));
       }
       conv_fwd(T, convs[B.fc2], pa.A, qa.A, P.TMP, Q.TMP, nullptr, nullptr, 1.f, th, th_t, st);
-      launch_add2<AT>(P.X[l + 1], T ? Q.X[l + 1] : nullptr, pa.X2, T ? qa.X2 : nullptr, P.TMP, T ? Q.TMP : nullptr,
-                      (int64_t)M * D, st);
+      if (!(MDD_VIT_FUSE_ADD_LN && l + 1 < vit.depth))    // otherwise formed by the next layer's first LayerNorm
+        launch_add2<AT>(P.X[l + 1], T ? Q.X[l + 1] : nullptr, pa.X2, T ? qa.X2 : nullptr, P.TMP, T ? Q.TMP : nullptr,
+                        (int64_t)M * D, st);
     }
     // feature = LayerNorm(x_L)[:, 0]: normalise the class rows only
     launch_cls_gather<AT>(T ? Q.CLS : P.CLS, T ? Q.X[vit.depth] : P.X[vit.depth], N, Tk, D, st);

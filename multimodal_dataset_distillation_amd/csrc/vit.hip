@@ -68,7 +68,11 @@ template <class S, class AT, int MAXC>
 __global__ __launch_bounds__(256) void k_ln_fwd(const AT* __restrict__ x, const AT* __restrict__ x_t,
                                                 const float* __restrict__ g, const float* __restrict__ g_t,
                                                 const float* __restrict__ b, const float* __restrict__ b_t,
-                                                AT* __restrict__ y, AT* __restrict__ y_t, int rows, int dim, float eps) {
+                                                AT* __restrict__ y, AT* __restrict__ y_t, int rows, int dim, float eps,
+                                                const AT* __restrict__ ra, const AT* __restrict__ rb, AT* __restrict__ rs) {
+  // ra / rb / rs (mdd_op_add_layernorm): the normalised tensor is the residual sum ra + rb, which is formed here, stored to rs
+  // in the storage type and normalised AS STORED (what a separate add kernel followed by this one would see).  Primal call:
+  // x is unused, rs = ra + rb.  Tangent call: x = the primal sum (stashed), ra / rb / rs = the tangents.
   constexpr int CE = Chunk<AT>::N;
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;                       // wave-uniform
@@ -80,7 +84,26 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const AT* __restrict__ x, const 
   for (int i = 0; i < MAXC; ++i) {
     const int c = lane + 64 * i;
     if (c < cch) {
-      ldcS<S, AT>(x, x_t, (int64_t)row * cch + c, v[i]);
+      const int64_t ci = (int64_t)row * cch + c;
+      if (ra) {
+        float p0[CE], p1[CE], q[CE];
+        ldc<AT>(ra, ci, p0); ldc<AT>(rb, ci, p1);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) q[e] = p0[e] + p1[e];
+        stc<AT>(rs, ci, q);
+        if constexpr (sizeof(AT) == 2) Chunk<AT>::unpack(Chunk<AT>::pack(q), q);      // as stored
+        if constexpr (IsDual<S>::v) {
+          float pv[CE];
+          ldc<AT>(x, ci, pv);
+#pragma unroll
+          for (int e = 0; e < CE; ++e) v[i][e] = Dual(pv[e], q[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < CE; ++e) v[i][e] = q[e];
+        }
+      } else {
+        ldcS<S, AT>(x, x_t, ci, v[i]);
+      }
 #pragma unroll
       for (int e = 0; e < CE; ++e) sum = sum + v[i][e];
     }
@@ -744,15 +767,18 @@ inline int vgrid(int64_t items, int block = 256) {
 
 template <class AT>
 int ln_fwd(int rows, int dim, float eps, const void* x, const void* x_t, const float* g, const float* g_t,
-           const float* b, const float* b_t, void* y, void* y_t, hipStream_t st) {
+           const float* b, const float* b_t, void* y, void* y_t, hipStream_t st, const void* ra = nullptr,
+           const void* rb = nullptr, void* rs = nullptr) {
   const int cch = dim / Chunk<AT>::N, maxc = (cch + 63) / 64;
   const int grid = (rows + 3) / 4;
 #define LN_F(MC)                                                                                                \
   do {                                                                                                          \
-    if (x_t) k_ln_fwd<Dual, AT, MC><<<grid, 256, 0, st>>>((const AT*)x, (const AT*)x_t, g, g_t, b, b_t, (AT*)y,  \
-                                                          (AT*)y_t, rows, dim, eps);                            \
+    if (g_t) k_ln_fwd<Dual, AT, MC><<<grid, 256, 0, st>>>((const AT*)x, (const AT*)x_t, g, g_t, b, b_t, (AT*)y,  \
+                                                          (AT*)y_t, rows, dim, eps, (const AT*)ra, (const AT*)rb, \
+                                                          (AT*)rs);                                             \
     else k_ln_fwd<float, AT, MC><<<grid, 256, 0, st>>>((const AT*)x, nullptr, g, nullptr, b, nullptr, (AT*)y,    \
-                                                       nullptr, rows, dim, eps);                                \
+                                                       nullptr, rows, dim, eps, (const AT*)ra, (const AT*)rb,   \
+                                                       (AT*)rs);                                                \
   } while (0)
   if (maxc == 1) LN_F(1); else if (maxc == 2) LN_F(2); else if (maxc == 3) LN_F(3); else LN_F(4);
 #undef LN_F
@@ -938,6 +964,22 @@ int mdd_op_layernorm(int dtype, int rows, int dim, float eps, const void* x, con
   CHECK_ARG(dim % ce == 0 && dim / ce <= 256, "dim must be a multiple of the 16-byte chunk and at most 256 chunks");
   if (dtype == MDD_DTYPE_F32) ln_fwd<float>(rows, dim, eps, x, x_t, gamma, gamma_t, beta, beta_t, y, y_t, (hipStream_t)stream);
   else ln_fwd<bf16>(rows, dim, eps, x, x_t, gamma, gamma_t, beta, beta_t, y, y_t, (hipStream_t)stream);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int mdd_op_add_layernorm(int dtype, int rows, int dim, float eps, const void* a, const void* a_t, const void* b,
+                         const void* b_t, void* s, void* s_t, const float* gamma, const float* gamma_t, const float* beta,
+                         const float* beta_t, void* y, void* y_t, void* stream) {
+  CHECK_ARG(rows > 0 && dim > 0 && s && gamma && beta, "null pointer / empty problem");
+  const bool T = gamma_t != nullptr;
+  CHECK_ARG(T ? (a_t && b_t && s_t && beta_t && y_t) : (a && b && y), "primal call: a, b, s, y; tangent call: s (primal sum), a_t, b_t, s_t, y_t");
+  CHECK_ARG(dtype == MDD_DTYPE_F32 || dtype == MDD_DTYPE_BF16, "dtype");
+  const int ce = dtype == MDD_DTYPE_F32 ? 4 : 8;
+  CHECK_ARG(dim % ce == 0 && dim / ce <= 256, "dim must be a multiple of the 16-byte chunk and at most 256 chunks");
+  const void* ra = T ? a_t : a; const void* rb = T ? b_t : b; void* rs = T ? s_t : s;
+  if (dtype == MDD_DTYPE_F32) ln_fwd<float>(rows, dim, eps, s, s_t, gamma, gamma_t, beta, beta_t, y, y_t, (hipStream_t)stream, ra, rb, rs);
+  else ln_fwd<bf16>(rows, dim, eps, s, s_t, gamma, gamma_t, beta, beta_t, y, y_t, (hipStream_t)stream, ra, rb, rs);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

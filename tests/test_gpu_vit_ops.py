@@ -88,6 +88,35 @@ def test_layernorm_forward_backward_and_tangents(dtype, rows, dim, report):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_add_layernorm_equals_add_then_layernorm(dtype, report):
+    """mdd_op_add_layernorm (the residual sum formed by the LayerNorm kernel that reads it) against the two separate steps:
+    bit-identical sum and output, primal and tangent call -- the sum is normalised as stored."""
+    mod, lib = _lib()
+    rows, dim, eps = 197 * 2, 768, 1e-6
+    g = torch.Generator().manual_seed(11)
+    rnd = lambda *s_: torch.randn(*s_, generator=g, dtype=torch.float64)
+    a, b, at, bt = (act(rnd(rows, dim), dtype) for _ in range(4))
+    gam, gamt, bet, bett = ((t.float().to(DEV)) for t in (1 + 0.2 * rnd(dim), 0.3 * rnd(dim), 0.1 * rnd(dim), 0.2 * rnd(dim)))
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # separate: s = a + b in the storage type, then LayerNorm
+    s_ref = (a.float() + b.float()).to(a.dtype)
+    st_ref = (at.float() + bt.float()).to(a.dtype)
+    y_ref, yt_ref = torch.empty_like(a), torch.empty_like(a)
+    mod.check(lib.mdd_op_layernorm(DT[dtype], rows, dim, eps, P(s_ref), None, P(gam), None, P(bet), None, P(y_ref), None, st))
+    mod.check(lib.mdd_op_layernorm(DT[dtype], rows, dim, eps, P(s_ref), P(st_ref), P(gam), P(gamt), P(bet), P(bett), P(y_ref),
+                                   P(yt_ref), st))
+    s_, st_, y, yt = (torch.empty_like(a) for _ in range(4))
+    mod.check(lib.mdd_op_add_layernorm(DT[dtype], rows, dim, eps, P(a), None, P(b), None, P(s_), None, P(gam), None, P(bet), None,
+                                       P(y), None, st))
+    mod.check(lib.mdd_op_add_layernorm(DT[dtype], rows, dim, eps, None, P(at), None, P(bt), P(s_), P(st_), P(gam), P(gamt), P(bet),
+                                       P(bett), None, P(yt), st))
+    torch.cuda.synchronize()
+    for got, want, name in ((s_, s_ref, "s"), (st_, st_ref, "s_t"), (y, y_ref, "y"), (yt, yt_ref, "y_t")):
+        assert torch.equal(got, want), name
+    report(f"add + layernorm {rows}x{dim} {dtype}: bit-identical to add then layernorm (s, s_t, y, y_t)")
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_gelu_forward_backward_and_tangents(dtype, report):
     mod, lib = _lib()
     g = torch.Generator().manual_seed(3)
