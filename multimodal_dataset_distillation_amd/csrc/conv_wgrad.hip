@@ -48,6 +48,11 @@
 #ifndef MDD_WGP_ABL
 #define MDD_WGP_ABL 0   // timing experiments on k_wgrad_pipe (wrong results): 1 no MFMAs, 2 no LDS-DMA, 4 no fragment reads, 8 no write-out
 #endif
+#ifndef MDD_WGP_GROUP_SPLITS
+#define MDD_WGP_GROUP_SPLITS 1   // pixel chunks of a grouped launch (0 = the cost model's choice): with ONE chunk the 108 tiles of a ViT layer go
+                                 // straight into the gradient -- no partial tiles, no combine launch, and 148 CUs stay with the other stream
+                                 // (measured: 1 chunk 407.0, 2 chunks (the model) 409.8, 3 chunks 418.4 ms per configs[4] iteration)
+#endif
 #ifndef MDD_WGP_SLOTS
 #define MDD_WGP_SLOTS 8    // half-tile slots of k_wgrad_pipe's LDS ring (16 KB each); half-tiles are issued SLOTS-2 phases ahead
 #endif
@@ -529,6 +534,7 @@ struct WProb {
 struct WGroup {
   WProb pr[4];
   int n, M, mchunk, tiles;
+  int direct;                  // one pixel chunk: the tiles are stored straight into dW (no slab, no combine)
   float* slab; int64_t slab_stride;
 };
 __global__ __launch_bounds__(512, 1) void k_wgrad_pipe(const WGroup pg) {
@@ -762,7 +768,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_pipe(const WGroup pg) {
 
   // ---- write-out: rows = k' (4 consecutive per lane), columns = co, as the one-stage kernel
   float* dst = pg.slab ? pg.slab + (size_t)bsplit * pg.slab_stride + q_.slab_off : q_.dW;
-  const bool plain = pg.slab != nullptr;
+  const bool plain = pg.slab != nullptr || pg.direct != 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -1110,7 +1116,7 @@ bool launch_pipe_group(const WItem* it, int n, int M, float* slab, int64_t slab_
   }
   const int nsrc = it[0].dy2 ? 2 : 1;
   const double out_mb = (double)out_floats * 4.0 / 1e6;
-  const bool two_phase = slab != nullptr && slab_floats >= out_floats && aligned;
+  bool two_phase = slab != nullptr && slab_floats >= out_floats && aligned;
   const double comb_us_per_mb = two_phase ? 0.6 : 1.0 / 1.3;
   int maxsplits = M / 256;     // at least four K-tiles per block
   if (two_phase && maxsplits > slab_floats / out_floats) maxsplits = (int)(slab_floats / out_floats);
@@ -1124,9 +1130,12 @@ bool launch_pipe_group(const WItem* it, int n, int M, float* slab, int64_t slab_
     const double t = waves * (steps * 0.9 + 8.0) + out_mb * sp * comb_us_per_mb;
     if (t < best) { best = t; splits = sp; }
   }
+  if (MDD_WGP_GROUP_SPLITS > 0 && n > 1) splits = MDD_WGP_GROUP_SPLITS;
   int mchunk = ((M + splits - 1) / splits + 63) / 64 * 64;
   splits = (M + mchunk - 1) / mchunk;
   G.n = n; G.M = M; G.mchunk = mchunk; G.tiles = tiles;
+  G.direct = (splits == 1 && aligned) ? 1 : 0;
+  if (G.direct) two_phase = false;
   G.slab = two_phase ? slab : nullptr;
   G.slab_stride = out_floats;
   static std::atomic<uint64_t> attr_devs{0};
