@@ -48,6 +48,9 @@
 #ifndef MDD_WGP_ABL
 #define MDD_WGP_ABL 0   // timing experiments on k_wgrad_pipe (wrong results): 1 no MFMAs, 2 no LDS-DMA, 4 no fragment reads, 8 no write-out
 #endif
+#ifndef MDD_WG_TSTEP_SCALE
+#define MDD_WG_TSTEP_SCALE 1.0   // split policy of k_conv_wgrad: < 1 weighs a K-step less = fewer, longer blocks (less slab traffic, less CU time)
+#endif
 #ifndef MDD_WGP_GROUP_SPLITS
 #define MDD_WGP_GROUP_SPLITS 1   // pixel chunks of a grouped launch (0 = the cost model's choice): with ONE chunk the 108 tiles of a ViT layer go
                                  // straight into the gradient -- no partial tiles, no combine launch, and 148 CUs stay with the other stream
@@ -1188,7 +1191,7 @@ void launch_cfg(WArgs a, float* slab, int64_t slab_floats, hipEvent_t ev_mid, hi
   // streamed read of the partial tile (~5 TB/s each)
   const double comb_us_per_mb = two_phase ? 0.6 : 1.0 / 1.3;
   const int slots = 256 * 3;   // resident blocks on the chip at ~3 blocks per CU
-  const double tstep = (g.k == 1 && g.stride == 1) ? 0.8 : 1.4;   // us per K-step (pointwise / gathered)
+  const double tstep = MDD_WG_TSTEP_SCALE * ((g.k == 1 && g.stride == 1) ? 0.8 : 1.4);   // us per K-step (pointwise / gathered)
   int maxsplits = (a.M + 2 * BKM - 1) / (2 * BKM);
   if (two_phase && maxsplits > slab_floats / out_floats) maxsplits = (int)(slab_floats / out_floats);
   if (maxsplits < 1) maxsplits = 1;
