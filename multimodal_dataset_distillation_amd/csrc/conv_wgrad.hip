@@ -57,7 +57,8 @@
                                  // (measured: 1 chunk 407.0, 2 chunks (the model) 409.8, 3 chunks 418.4 ms per configs[4] iteration)
 #endif
 #ifndef MDD_WGP_SLOTS
-#define MDD_WGP_SLOTS 8    // half-tile slots of k_wgrad_pipe's LDS ring (16 KB each); half-tiles are issued SLOTS-2 phases ahead
+#define MDD_WGP_SLOTS 8    // half-tile slots of k_wgrad_pipe's LDS ring (16 KB each); half-tiles are issued SLOTS-2 phases ahead.  The K loop is
+                           // unrolled over EIGHT slots (static_assert): the 10-slot experiment of profiles/r03_experiments.md predates that
 #endif
 #ifndef MDD_WG_BKM
 #define MDD_WG_BKM 64      // pixels per K-step of the bf16 instances
