@@ -1134,7 +1134,7 @@ bool launch_pipe_group(const WItem* it, int n, int M, float* slab, int64_t slab_
     const double t = waves * (steps * 0.9 + 8.0) + out_mb * sp * comb_us_per_mb;
     if (t < best) { best = t; splits = sp; }
   }
-  if (MDD_WGP_GROUP_SPLITS > 0 && n > 1) splits = MDD_WGP_GROUP_SPLITS;
+  if (MDD_WGP_GROUP_SPLITS > 0 && n > 1 && tiles * MDD_WGP_GROUP_SPLITS >= 64) splits = MDD_WGP_GROUP_SPLITS;   // small groups: the model
   int mchunk = ((M + splits - 1) / splits + 63) / 64 * 64;
   splits = (M + mchunk - 1) / mchunk;
   G.n = n; G.M = M; G.mchunk = mchunk; G.tiles = tiles;
